@@ -1,0 +1,567 @@
+// fr_api.hip — host side of libfr_raster.so: the C ABI of include/fr_raster.h.
+//
+// Owns device memory (glyph tables, root records, job tables), validates what the
+// caller hands over, and launches the kernels of fr_prepare.hip / fr_render.hip /
+// fr_exact.hip on the context's HIP stream.  No CPU rasterization path exists here:
+// without a usable gfx950 device every compute entry point returns FR_E_HIP.
+#include "../../include/fr_raster.h"
+#include "fr_device.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace fr {
+void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, RecBounds *,
+                    RecPayload *, uint32_t *, hipStream_t);
+hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
+size_t render_lds_bytes(uint32_t strip_w, int n, uint32_t kmax);
+void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
+                       uint8_t *, hipStream_t);
+void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
+                          uint32_t, const int16_t *, uint64_t, uint32_t, int, int, int16_t *,
+                          hipStream_t);
+}  // namespace fr
+
+static_assert(sizeof(fr_job) == sizeof(fr::Job), "fr_job layout");
+static_assert(sizeof(fr_job) == 32, "fr_job is 32 bytes");
+
+// --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "%s: %s", #expr,  \
+                        hipGetErrorString(e_));                                              \
+    } while (0)
+
+struct fr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    uint32_t kmax = 32;          // crossings kept per sample row before the direct-sum fallback
+    uint32_t max_cols = 2048;    // sample columns per strip (LDS table of cx)
+};
+
+struct fr_glyphset {
+    fr_ctx *ctx = nullptr;
+    uint32_t n_glyphs = 0, n_contours = 0, n_seg = 0;
+    uint64_t n_points = 0;
+    int16_t *d_pts = nullptr;
+    uint32_t *d_seg_p0 = nullptr, *d_seg_prev = nullptr, *d_glyph_seg_start = nullptr, *d_rec_count = nullptr;
+    fr::RecBounds *d_bounds = nullptr;
+    fr::RecPayload *d_payload = nullptr;
+};
+
+struct fr_plan {
+    fr_ctx *ctx = nullptr;
+    const fr_glyphset *gs = nullptr;
+    fr::Job *d_jobs = nullptr;
+    uint32_t n_jobs = 0;
+    fr_raster_params params{};
+    uint32_t bands = 0, strips = 0, strip_w = 0;
+    uint64_t pixels = 0, need_cols = 0, need_rows = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+extern "C" {
+
+int fr_abi_version(void) { return FR_ABI_VERSION; }
+const char *fr_last_error(void) { return g_err; }
+
+int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
+{
+    if (!out) return fail(FR_E_INVALID, "fr_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(FR_E_HIP, "fr_ctx_create: no HIP device (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+    if (device < 0 || device >= n) return fail(FR_E_INVALID, "fr_ctx_create: device %d of %d", device, n);
+    HIP_TRY(hipSetDevice(device));
+    fr_ctx *c = new (std::nothrow) fr_ctx;
+    if (!c) return fail(FR_E_NOMEM, "fr_ctx_create: host allocation");
+    c->device = device;
+    if (hip_stream) {
+        c->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(FR_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return FR_OK;
+}
+
+void fr_ctx_destroy(fr_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int fr_ctx_sync(fr_ctx *ctx)
+{
+    if (!ctx) return fail(FR_E_INVALID, "fr_ctx_sync: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return fail(FR_E_INVALID, "fr_ctx_set_option: NULL argument");
+    if (!strcmp(key, "kmax")) {
+        if (value < 1 || value > 128) return fail(FR_E_INVALID, "kmax must be in [1,128]");
+        ctx->kmax = (uint32_t)value;
+        return FR_OK;
+    }
+    if (!strcmp(key, "max_cols")) {
+        if (value < 64 || value > 8192 || (value % 64)) return fail(FR_E_INVALID, "max_cols must be a multiple of 64 in [64,8192]");
+        ctx->max_cols = (uint32_t)value;
+        return FR_OK;
+    }
+    return fail(FR_E_INVALID, "fr_ctx_set_option: unknown key '%s'", key);
+}
+
+// ---- glyph tables --------------------------------------------------------
+// Builds, per curve, the point index of its p0 and of the previous curve's p0 in the
+// same contour (wrapping to the last curve: render_glyph.zig:126-127).
+static int flatten_segments(const uint32_t *contour_start, uint32_t n_contours, uint64_t *n_points,
+                            std::vector<uint32_t> &seg_p0, std::vector<uint32_t> &seg_prev,
+                            std::vector<uint32_t> *contour_seg_start)
+{
+    if (n_contours && !contour_start) return fail(FR_E_INVALID, "contour_start is NULL");
+    uint64_t np = n_contours ? contour_start[n_contours] : 0;
+    if (n_contours && contour_start[0] != 0) return fail(FR_E_INVALID, "contour_start[0] must be 0");
+    if (contour_seg_start) contour_seg_start->assign(1, 0u);
+    for (uint32_t c = 0; c < n_contours; ++c) {
+        if (contour_start[c + 1] < contour_start[c]) return fail(FR_E_INVALID, "contour_start not monotone at %u", c);
+        const uint32_t len = contour_start[c + 1] - contour_start[c];
+        // points.len = 2*curves + 1 (Glyph.zig:23); an even length would index past the
+        // slice in the reference (render_glyph.zig:42)
+        if (len != 0 && (len & 1u) == 0) return fail(FR_E_INVALID, "contour %u has even length %u", c, len);
+        const uint32_t curves = len / 2;                                    // render_glyph.zig:38
+        for (uint32_t k = 0; k < curves; ++k) {
+            seg_p0.push_back(contour_start[c] + 2 * k);
+            seg_prev.push_back(contour_start[c] + (k != 0 ? 2 * k - 2 : len - 3));
+        }
+        if (contour_seg_start) contour_seg_start->push_back((uint32_t)seg_p0.size());
+    }
+    *n_points = np;
+    return FR_OK;
+}
+
+void fr_glyphset_destroy(fr_glyphset *gs)
+{
+    if (!gs) return;
+    (void)hipSetDevice(gs->ctx->device);
+    (void)hipStreamSynchronize(gs->ctx->stream);
+    dfree(gs->d_pts); dfree(gs->d_seg_p0); dfree(gs->d_seg_prev); dfree(gs->d_glyph_seg_start);
+    dfree(gs->d_rec_count); dfree(gs->d_bounds); dfree(gs->d_payload);
+    delete gs;
+}
+
+int fr_glyphset_prepare(fr_glyphset *gs)
+{
+    if (!gs) return fail(FR_E_INVALID, "fr_glyphset_prepare: NULL");
+    HIP_TRY(hipSetDevice(gs->ctx->device));
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, gs->n_glyphs, gs->d_bounds,
+                       gs->d_payload, gs->d_rec_count, gs->ctx->stream);
+    HIP_TRY(hipGetLastError());
+    return FR_OK;
+}
+
+int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, const uint32_t *glyph_start, uint32_t n_glyphs,
+                       fr_glyphset **out)
+{
+    if (!ctx || !out) return fail(FR_E_INVALID, "fr_glyphset_create: NULL argument");
+    *out = nullptr;
+    if (n_glyphs && !glyph_start) return fail(FR_E_INVALID, "glyph_start is NULL");
+    if (n_glyphs && (glyph_start[0] != 0 || glyph_start[n_glyphs] != n_contours))
+        return fail(FR_E_INVALID, "glyph_start must run from 0 to n_contours");
+    std::vector<uint32_t> seg_p0, seg_prev, cseg;
+    uint64_t np = 0;
+    int rc = flatten_segments(contour_start, n_contours, &np, seg_p0, seg_prev, &cseg);
+    if (rc) return rc;
+    if (np && !points_xy) return fail(FR_E_INVALID, "points_xy is NULL");
+    if (seg_p0.size() > 0x7fffffffull) return fail(FR_E_UNSUPPORTED, "too many segments");
+    std::vector<uint32_t> gseg(n_glyphs + 1, 0u);
+    for (uint32_t g = 0; g < n_glyphs; ++g) {
+        if (glyph_start[g + 1] < glyph_start[g] || glyph_start[g + 1] > n_contours)
+            return fail(FR_E_INVALID, "glyph_start not monotone at %u", g);
+        gseg[g + 1] = cseg[glyph_start[g + 1]];
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    fr_glyphset *gs = new (std::nothrow) fr_glyphset;
+    if (!gs) return fail(FR_E_NOMEM, "fr_glyphset_create: host allocation");
+    gs->ctx = ctx; gs->n_glyphs = n_glyphs; gs->n_contours = n_contours;
+    gs->n_seg = (uint32_t)seg_p0.size(); gs->n_points = np;
+    const size_t nseg1 = gs->n_seg ? gs->n_seg : 1, np1 = np ? np : 1;
+#define GS_TRY(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fr_glyphset_destroy(gs);                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "%s: %s", #expr,   \
+                        hipGetErrorString(e_));                                               \
+        }                                                                                     \
+    } while (0)
+    GS_TRY(hipMalloc(&gs->d_pts, np1 * 2 * sizeof(int16_t) + 16));
+    GS_TRY(hipMalloc(&gs->d_seg_p0, nseg1 * 4));
+    GS_TRY(hipMalloc(&gs->d_seg_prev, nseg1 * 4));
+    GS_TRY(hipMalloc(&gs->d_glyph_seg_start, ((size_t)n_glyphs + 1) * 4));
+    GS_TRY(hipMalloc(&gs->d_rec_count, ((size_t)n_glyphs + 1) * 4));
+    GS_TRY(hipMalloc(&gs->d_bounds, 2 * nseg1 * sizeof(fr::RecBounds)));
+    GS_TRY(hipMalloc(&gs->d_payload, 2 * nseg1 * sizeof(fr::RecPayload)));
+    hipStream_t st = ctx->stream;
+    if (np) GS_TRY(hipMemcpyAsync(gs->d_pts, points_xy, np * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    if (gs->n_seg) {
+        GS_TRY(hipMemcpyAsync(gs->d_seg_p0, seg_p0.data(), (size_t)gs->n_seg * 4, hipMemcpyHostToDevice, st));
+        GS_TRY(hipMemcpyAsync(gs->d_seg_prev, seg_prev.data(), (size_t)gs->n_seg * 4, hipMemcpyHostToDevice, st));
+    }
+    GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
+    GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, n_glyphs, gs->d_bounds,
+                       gs->d_payload, gs->d_rec_count, st);
+    GS_TRY(hipGetLastError());
+    GS_TRY(hipStreamSynchronize(st));   // host vectors above die with this frame
+#undef GS_TRY
+    *out = gs;
+    return FR_OK;
+}
+
+int fr_glyphset_stats(const fr_glyphset *gs, uint64_t *n_segments, uint64_t *n_records)
+{
+    if (!gs) return fail(FR_E_INVALID, "fr_glyphset_stats: NULL");
+    HIP_TRY(hipSetDevice(gs->ctx->device));
+    if (n_segments) *n_segments = gs->n_seg;
+    if (n_records) {
+        std::vector<uint32_t> cnt(gs->n_glyphs + 1);
+        HIP_TRY(hipStreamSynchronize(gs->ctx->stream));
+        HIP_TRY(hipMemcpy(cnt.data(), gs->d_rec_count, ((size_t)gs->n_glyphs) * 4, hipMemcpyDeviceToHost));
+        uint64_t t = 0;
+        for (uint32_t g = 0; g < gs->n_glyphs; ++g) t += cnt[g];
+        *n_records = t;
+    }
+    return FR_OK;
+}
+
+// ---- plans ----------------------------------------------------------------
+static int check_params(const fr_raster_params *p)
+{
+    if (!p) return fail(FR_E_INVALID, "params is NULL");
+    if (p->mode < FR_WINDING_I16 || p->mode > FR_COVERAGE_U8) return fail(FR_E_INVALID, "unknown mode %d", p->mode);
+    const int n = p->samples_per_axis;
+    if (p->mode == FR_COVERAGE_U8) {
+        if (n != 1 && n != 2 && n != 4) return fail(FR_E_UNSUPPORTED, "samples_per_axis %d not in {1,2,4}", n);
+    } else if (n != 1) {
+        return fail(FR_E_INVALID, "samples_per_axis must be 1 for mode %d", p->mode);
+    }
+    if (p->sample_phase != FR_SAMPLE_CORNER && p->sample_phase != FR_SAMPLE_CENTER)
+        return fail(FR_E_INVALID, "unknown sample_phase %d", p->sample_phase);
+    return FR_OK;
+}
+
+void fr_plan_destroy(fr_plan *plan)
+{
+    if (!plan) return;
+    (void)hipSetDevice(plan->ctx->device);
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    dfree(plan->d_jobs);
+    if (plan->ev0) (void)hipEventDestroy(plan->ev0);
+    if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+    delete plan;
+}
+
+int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
+                   const fr_raster_params *params, fr_plan **out)
+{
+    if (!ctx || !gs || !out) return fail(FR_E_INVALID, "fr_plan_create: NULL argument");
+    *out = nullptr;
+    if (gs->ctx != ctx) return fail(FR_E_INVALID, "glyph set belongs to another context");
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (n_jobs && !jobs) return fail(FR_E_INVALID, "jobs is NULL");
+    const uint32_t n = (uint32_t)params->samples_per_axis;
+    uint32_t max_w = 0, max_h = 0;
+    uint64_t pixels = 0, need_cols = 0, need_rows = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const fr_job &jb = jobs[j];
+        if (jb.glyph >= gs->n_glyphs) return fail(FR_E_INVALID, "job %u: glyph %u of %u", j, jb.glyph, gs->n_glyphs);
+        if (!(jb.scale > 0.0f) || !std::isfinite(jb.scale)) return fail(FR_E_INVALID, "job %u: scale must be finite and > 0", j);
+        if (jb.w > 65535u || jb.h > 65535u) return fail(FR_E_UNSUPPORTED, "job %u: cell larger than 65535", j);
+        // sample coordinates must be exactly representable in binary32
+        if (jb.min_x < -(1 << 22) || (int64_t)jb.min_x + jb.w > (1 << 22) || jb.max_y > (1 << 22) ||
+            (int64_t)jb.max_y - jb.h < -(1 << 22))
+            return fail(FR_E_UNSUPPORTED, "job %u: pixel coordinates beyond +-2^22", j);
+        max_w = jb.w > max_w ? jb.w : max_w;
+        max_h = jb.h > max_h ? jb.h : max_h;
+        pixels += (uint64_t)jb.w * jb.h;
+        need_cols = std::max<uint64_t>(need_cols, (uint64_t)jb.out_x + jb.w);
+        need_rows = std::max<uint64_t>(need_rows, (uint64_t)jb.out_y + jb.h);
+    }
+    fr_plan *p = new (std::nothrow) fr_plan;
+    if (!p) return fail(FR_E_NOMEM, "fr_plan_create: host allocation");
+    p->ctx = ctx; p->gs = gs; p->n_jobs = n_jobs; p->params = *params;
+    p->pixels = pixels; p->need_cols = need_cols; p->need_rows = need_rows;
+    const uint32_t band = 256u / n;
+    const uint32_t cap_w = (ctx->max_cols / n) & ~15u;                  // strip width cap, pixels
+    uint32_t sw = (max_w + 15u) & ~15u;
+    if (sw > cap_w) sw = cap_w;
+    if (sw == 0) sw = 16;
+    p->strip_w = sw;
+    p->bands = max_h ? (max_h + band - 1) / band : 1;
+    p->strips = max_w ? (max_w + sw - 1) / sw : 1;
+    if ((uint64_t)n_jobs * p->bands * p->strips > 0x7fffffffull) {
+        delete p;
+        return fail(FR_E_UNSUPPORTED, "batch needs more than 2^31 workgroups; split it");
+    }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
+    if (e == hipSuccess && n_jobs)
+        e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+    if (e != hipSuccess) {
+        fr_plan_destroy(p);
+        return fail(e == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "fr_plan_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return FR_OK;
+}
+
+uint64_t fr_plan_pixels(const fr_plan *plan) { return plan ? plan->pixels : 0; }
+
+static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
+{
+    if (!plan) return fail(FR_E_INVALID, "plan is NULL");
+    if (plan->n_jobs == 0) return FR_OK;
+    if (!out_dev) return fail(FR_E_INVALID, "out is NULL");
+    if (plan->need_cols > out_stride || plan->need_rows > out_rows)
+        return fail(FR_E_INVALID, "jobs need %llu x %llu elements, output is %zu x %zu",
+                    (unsigned long long)plan->need_cols, (unsigned long long)plan->need_rows, out_stride, out_rows);
+    fr::RenderArgs a;
+    a.jobs = plan->d_jobs;
+    a.glyph_seg_start = plan->gs->d_glyph_seg_start;
+    a.glyph_rec_count = plan->gs->d_rec_count;
+    a.bounds = plan->gs->d_bounds;
+    a.payload = plan->gs->d_payload;
+    a.out = out_dev;
+    a.out_stride = out_stride;
+    a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
+    a.kmax = plan->ctx->kmax;
+    a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
+    HIP_TRY(hipSetDevice(plan->ctx->device));
+    HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
+    return FR_OK;
+}
+
+int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
+{
+    return plan_launch(plan, out_dev, out_stride, out_rows);
+}
+
+int fr_plan_render_timed(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows, float *ms)
+{
+    if (!plan || !ms) return fail(FR_E_INVALID, "fr_plan_render_timed: NULL argument");
+    HIP_TRY(hipSetDevice(plan->ctx->device));
+    HIP_TRY(hipEventRecord(plan->ev0, plan->ctx->stream));
+    int rc = plan_launch(plan, out_dev, out_stride, out_rows);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(plan->ev1, plan->ctx->stream));
+    HIP_TRY(hipEventSynchronize(plan->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, plan->ev0, plan->ev1));
+    return FR_OK;
+}
+
+int fr_render_batch(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
+                    const fr_raster_params *params, void *out_host, size_t out_stride, size_t out_rows)
+{
+    fr_plan *plan = nullptr;
+    int rc = fr_plan_create(ctx, gs, jobs, n_jobs, params, &plan);
+    if (rc) return rc;
+    if (n_jobs == 0) { fr_plan_destroy(plan); return FR_OK; }
+    if (!out_host) { fr_plan_destroy(plan); return fail(FR_E_INVALID, "out_host is NULL"); }
+    const size_t esz = params->mode == FR_WINDING_I16 ? 2 : 1;
+    const size_t bytes = out_stride * out_rows * esz;
+    void *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_out, bytes ? bytes : 16);
+    // pixels outside every job keep the caller's bytes: stage the buffer in first
+    if (e == hipSuccess) e = hipMemcpyAsync(d_out, out_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = plan_launch(plan, d_out, out_stride, out_rows);
+        if (rc == FR_OK) {
+            e = hipMemcpyAsync(out_host, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    if (d_out) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_out); }
+    fr_plan_destroy(plan);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "fr_render_batch: %s", hipGetErrorString(e));
+    return FR_OK;
+}
+
+// ---- renderGlyph drop-in ----------------------------------------------------
+// render_glyph.zig:13-19, host arithmetic in binary32 exactly as written there.
+int fr_render_glyph_dims(const int16_t box[4], uint16_t units_per_em, uint16_t font_size,
+                         int16_t min_corner[2], int16_t max_corner[2], uint16_t *width,
+                         uint16_t *height, float *scale_out)
+{
+    if (!box || !min_corner || !max_corner || !width || !height) return fail(FR_E_INVALID, "fr_render_glyph_dims: NULL argument");
+    if (units_per_em == 0 || font_size == 0) return fail(FR_E_INVALID, "units_per_em and font_size must be > 0");
+    const float scale = (float)font_size / (float)units_per_em;                    // :13
+    const float b[4] = {(float)box[0] * scale, (float)box[1] * scale, (float)box[2] * scale, (float)box[3] * scale};   // :15
+    const float lo0 = std::floor(b[0]), lo1 = std::floor(b[1]), hi0 = std::ceil(b[2]), hi1 = std::ceil(b[3]);
+    if (lo0 < -32768.f || lo1 < -32768.f || hi0 > 32767.f || hi1 > 32767.f)
+        return fail(FR_E_UNSUPPORTED, "scaled box leaves i16 (the reference's @intFromFloat would trap)");
+    min_corner[0] = (int16_t)lo0; min_corner[1] = (int16_t)lo1;                    // :16
+    max_corner[0] = (int16_t)hi0; max_corner[1] = (int16_t)hi1;                    // :17
+    const int w = (int)max_corner[0] - min_corner[0] + 1, h = (int)max_corner[1] - min_corner[1] + 1;   // :18-19
+    if (w < 1 || h < 1 || w > 32767 || h > 32767) return fail(FR_E_UNSUPPORTED, "image size leaves i16");
+    *width = (uint16_t)w; *height = (uint16_t)h;
+    if (scale_out) *scale_out = scale;
+    return FR_OK;
+}
+
+int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                    uint32_t n_contours, const int16_t box[4], uint16_t units_per_em,
+                    uint16_t font_size, int32_t mode, void *out_host)
+{
+    if (!ctx) return fail(FR_E_INVALID, "ctx is NULL");
+    int16_t mn[2], mx[2];
+    uint16_t w, h;
+    float scale;
+    int rc = fr_render_glyph_dims(box, units_per_em, font_size, mn, mx, &w, &h, &scale);
+    if (rc) return rc;
+    const uint32_t gstart[2] = {0, n_contours};
+    const uint32_t zero_start[1] = {0};
+    fr_glyphset *gs = nullptr;
+    rc = fr_glyphset_create(ctx, points_xy, n_contours ? contour_start : zero_start, n_contours, gstart, 1, &gs);
+    if (rc) return rc;
+    fr_job jb{};
+    jb.glyph = 0; jb.min_x = mn[0]; jb.max_y = mx[1]; jb.w = w; jb.h = h; jb.out_x = 0; jb.out_y = 0; jb.scale = scale;
+    fr_raster_params prm{};
+    prm.mode = mode; prm.samples_per_axis = 1; prm.sample_phase = FR_SAMPLE_CORNER;
+    rc = fr_render_batch(ctx, gs, &jb, 1, &prm, out_host, w, h);
+    fr_glyphset_destroy(gs);
+    return rc;
+}
+
+// ---- exact-integer path ---------------------------------------------------
+struct ExactDev {
+    int16_t *pts = nullptr;
+    uint32_t *seg_p0 = nullptr, *seg_prev = nullptr;
+    uint8_t *ctype = nullptr, *inc = nullptr;
+    uint32_t n_seg = 0;
+    ~ExactDev() { dfree(pts); dfree(seg_p0); dfree(seg_prev); dfree(ctype); dfree(inc); }
+};
+
+static int exact_setup(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, ExactDev &d)
+{
+    if (!ctx) return fail(FR_E_INVALID, "ctx is NULL");
+    std::vector<uint32_t> seg_p0, seg_prev;
+    uint64_t np = 0;
+    int rc = flatten_segments(contour_start, n_contours, &np, seg_p0, seg_prev, nullptr);
+    if (rc) return rc;
+    if (np && !points_xy) return fail(FR_E_INVALID, "points_xy is NULL");
+    d.n_seg = (uint32_t)seg_p0.size();
+    const size_t ns1 = d.n_seg ? d.n_seg : 1, np1 = np ? np : 1;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(&d.pts, np1 * 4 + 16));
+    HIP_TRY(hipMalloc(&d.seg_p0, ns1 * 4));
+    HIP_TRY(hipMalloc(&d.seg_prev, ns1 * 4));
+    HIP_TRY(hipMalloc(&d.ctype, ns1));
+    HIP_TRY(hipMalloc(&d.inc, ns1));
+    if (np) HIP_TRY(hipMemcpyAsync(d.pts, points_xy, np * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (d.n_seg) {
+        HIP_TRY(hipMemcpyAsync(d.seg_p0, seg_p0.data(), (size_t)d.n_seg * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d.seg_prev, seg_prev.data(), (size_t)d.n_seg * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    fr::launch_glyph_info(d.pts, d.seg_p0, d.seg_prev, d.n_seg, d.ctype, d.inc, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+int fr_glyph_info_init(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, uint8_t *curve_type, uint8_t *include_p0)
+{
+    ExactDev d;
+    int rc = exact_setup(ctx, points_xy, contour_start, n_contours, d);
+    if (rc) return rc;
+    if (d.n_seg) {
+        if (!curve_type || !include_p0) return fail(FR_E_INVALID, "output is NULL");
+        HIP_TRY(hipMemcpy(curve_type, d.ctype, d.n_seg, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(include_p0, d.inc, d.n_seg, hipMemcpyDeviceToHost));
+    }
+    return FR_OK;
+}
+
+static int exact_run(fr_ctx *ctx, ExactDev &d, const int16_t *query_xy, uint64_t n_query,
+                     uint32_t lat_w, int x_min, int y_max, int16_t *out_host)
+{
+    if (n_query == 0) return FR_OK;
+    if (!out_host) return fail(FR_E_INVALID, "output is NULL");
+    if (n_query > 0xffffffffull * 256ull) return fail(FR_E_UNSUPPORTED, "too many query points");
+    int16_t *d_q = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_out, n_query * 2);
+    if (e == hipSuccess && query_xy) e = hipMalloc(&d_q, n_query * 4);
+    if (e == hipSuccess && query_xy) e = hipMemcpyAsync(d_q, query_xy, n_query * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        fr::launch_exact_winding(d.pts, d.seg_p0, d.ctype, d.inc, d.n_seg, d_q, n_query, lat_w, x_min, y_max, d_out, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, n_query * 2, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = e2;
+    dfree(d_q); dfree(d_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "exact winding: %s", hipGetErrorString(e));
+    return FR_OK;
+}
+
+int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                        uint32_t n_contours, const int16_t *query_xy, uint32_t n_query,
+                        int16_t *out_winding)
+{
+    if (n_query && !query_xy) return fail(FR_E_INVALID, "query_xy is NULL");
+    ExactDev d;
+    int rc = exact_setup(ctx, points_xy, contour_start, n_contours, d);
+    if (rc) return rc;
+    return exact_run(ctx, d, query_xy, n_query, 1, 0, 0, out_winding);
+}
+
+int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, const int16_t box[4], int16_t *out_host)
+{
+    if (!box) return fail(FR_E_INVALID, "box is NULL");
+    const int W = (int)box[2] - box[0] + 3, H = (int)box[3] - box[1] + 3;       // Image.zig:183
+    if (W < 1 || H < 1) return fail(FR_E_INVALID, "empty box");
+    ExactDev d;
+    int rc = exact_setup(ctx, points_xy, contour_start, n_contours, d);
+    if (rc) return rc;
+    return exact_run(ctx, d, nullptr, (uint64_t)W * H, (uint32_t)W, box[0], box[3], out_host);
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// fr_device.hpp — shared device-side definitions for the gfx950 glyph rasterizer.
+//
+// Arithmetic contract: the reference's glyphWindingAt
+// (/root/reference/src/tools/render_glyph.zig:35-73) is strict IEEE-754 binary32
+// with no fused multiply-add.  Every translation unit that includes this header is
+// compiled with -ffp-contract=off and keeps hipcc's default correctly-rounded
+// f32 divide / sqrt; the pragma below makes the first part independent of flags.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace fr {
+
+// ---------------------------------------------------------------------------
+// Root records.  One quadratic segment (p0,p1,p2) of a contour yields up to two
+// records (its t+ and t- root; render_glyph.zig:60-63) or one (the a == 0 branch,
+// :49-57).  A record keeps exactly the f32 constants the reference recomputes per
+// pixel, plus [lo, hi]: the closed interval of ray heights cy for which the
+// reference ACCEPTS this root (delta >= 0 and 0 <= t < 1, :52,:59,:64).  The
+// interval is exact, not an estimate — see fr_prepare.hip.
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(8))) RecBounds {
+    float lo, hi;
+};
+
+// payload, 32 B = two dwordx4:
+//   quadratic: a, B = p0y - p1y, c1 = p1y*p1y, c2 = p0y*p2y, Ax, Bx, p0x, flags
+//   linear   : 0, p0y,           den = p2y-p0y, 0,            Ax, Bx, p0x, flags
+//   Ax = (p0x - 2*p1x) + p2x, Bx = 2*(p1x - p0x)               (:53, :65)
+struct __attribute__((aligned(16))) RecPayload {
+    float a, b, c1, c2, ax, bx, p0x;
+    uint32_t flags;
+};
+enum : uint32_t {
+    REC_LINEAR = 1u,     // a == 0 branch
+    REC_NEG_ROOT = 2u,   // t- = (B - sqrt(delta)) / a ; otherwise t+
+    REC_LIN_MINUS = 4u   // linear branch adds -1 (p0y < p2y, :55) ; otherwise +1
+};
+
+struct Job {   // == fr_job (include/fr_raster.h)
+    uint32_t glyph;
+    int32_t min_x, max_y;
+    uint32_t w, h;
+    uint32_t out_x, out_y;
+    float scale;
+};
+
+// kernel arguments of render_kernel (fr_render.hip), filled by fr_api.hip
+struct RenderArgs {
+    const Job *jobs;
+    const uint32_t *glyph_seg_start;   // record slice of glyph g starts at 2*glyph_seg_start[g]
+    const uint32_t *glyph_rec_count;
+    const RecBounds *bounds;
+    const RecPayload *payload;
+    void *out;
+    uint64_t out_stride;               // elements
+    uint32_t n_jobs, bands, strips, strip_w, kmax;
+    int32_t phase_center;
+};
+
+// order-preserving map binary32 -> u32 (total order, -0 < +0)
+__host__ __device__ inline uint32_t f2key(float f)
+{
+    uint32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float key2f(uint32_t k)
+{
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
+// t of a record at ray height cy — the reference's operation order, one rounding
+// per operation:  delta = ((cy*a) + c1) - c2 (:58);  t = (B +/- sqrt(delta)) / a (:60-61)
+//                 linear: t = (cy - p0y) / (p2y - p0y) (:51)
+__device__ __forceinline__ float rec_t_quad(const RecPayload &r, float cy)
+{
+    float delta = cy * r.a + r.c1 - r.c2;
+    float sq = __builtin_sqrtf(delta);
+    float num = (r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq);
+    return num / r.a;
+}
+__device__ __forceinline__ float rec_t_lin(const RecPayload &r, float cy)
+{
+    return (cy - r.b) / r.c1;
+}
+// x of the crossing and the sign it adds (:53-55, :65-68)
+__device__ __forceinline__ void rec_cross(const RecPayload &r, float cy, float &xx, int &sgn)
+{
+    float t;
+    if (r.flags & REC_LINEAR) {
+        t = rec_t_lin(r, cy);
+        sgn = (r.flags & REC_LIN_MINUS) ? -1 : 1;
+    } else {
+        t = rec_t_quad(r, cy);
+        float dy = r.a * t + (-r.b);           // a*t + (p1y - p0y), :67
+        sgn = (dy > 0.0f) ? -1 : 1;            // :68
+    }
+    xx = (r.ax * t + r.bx) * t + r.p0x;        // :53 / :65
+}
+
+// sub-sample offset (k + phase)/n — exact in binary32 for n in {1,2,4}
+__device__ __forceinline__ float sub_off(int k, int n, int phase_center)
+{
+    return ((float)k + (phase_center ? 0.5f : 0.0f)) / (float)n;
+}
+
+}  // namespace fr

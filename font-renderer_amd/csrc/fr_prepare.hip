@@ -1,0 +1,133 @@
+// fr_prepare.hip — per-segment precompute: root records with EXACT acceptance intervals.
+//
+// Why an interval is exact.  For one root of one segment the reference decides
+// "accept" from (render_glyph.zig:58-64)
+//        delta = fl(fl(fl(cy*a) + c1) - c2);   reject if delta < 0
+//        t     = fl(fl(B +/- sqrt(delta)) / a); reject if t < 0 or t >= 1
+// with a, B, c1, c2 constants of the segment.  Every step is a correctly rounded
+// IEEE operation with one varying operand, hence a monotone function of it; so
+// delta(cy) is monotone (direction = sign a), sqrt is non-decreasing, and
+// t+(cy) is non-decreasing / t-(cy) non-increasing for either sign of a.  The
+// three rejection tests are therefore each a one-sided cut of the cy axis, and the
+// accepted set is a closed interval [lo, hi] of binary32 values.  We locate its two
+// ends by bisection over the ordered bit patterns of ALL finite floats, evaluating
+// the reference's own expression (rec_t_quad / rec_t_lin) at each probe — no error
+// analysis, no tolerance.  The same holds for the a == 0 branch (:51-52).
+// With [lo, hi] known the render kernel tests  lo <= cy <= hi  (two compares) instead
+// of solving the quadratic for every (row, segment), and rows outside it are culled
+// with a bit-exact guarantee.
+#include "fr_device.hpp"
+
+namespace fr {
+
+// 0 = cy lies below the accepted interval, 1 = accepted, 2 = above
+__device__ __forceinline__ int classify(const RecPayload &r, float cy)
+{
+    if (r.flags & REC_LINEAR) {
+        float t = rec_t_lin(r, cy);
+        bool up = r.c1 > 0.0f;                         // den > 0: t non-decreasing in cy
+        if (t < 0.0f) return up ? 0 : 2;               // :52
+        if (t >= 1.0f) return up ? 2 : 0;
+        return 1;
+    }
+    float delta = cy * r.a + r.c1 - r.c2;              // :58
+    if (delta < 0.0f) return (r.a > 0.0f) ? 0 : 2;     // :59
+    float t = rec_t_quad(r, cy);
+    bool neg = (r.flags & REC_NEG_ROOT) != 0;          // t- is non-increasing in cy
+    if (t < 0.0f) return neg ? 2 : 0;                  // :64
+    if (t >= 1.0f) return neg ? 0 : 2;
+    return 1;
+}
+
+__device__ inline bool accept_interval(const RecPayload &r, float &lo, float &hi)
+{
+    const uint32_t kmin = f2key(-3.402823466e+38f), kmax = f2key(3.402823466e+38f);
+    // first key whose class is >= 1
+    uint32_t a = kmin, b = kmax + 1u;
+    while (a < b) {
+        uint32_t mid = a + ((b - a) >> 1);
+        if (classify(r, key2f(mid)) >= 1) b = mid; else a = mid + 1u;
+    }
+    const uint32_t first = a;
+    // first key whose class is 2
+    a = kmin; b = kmax + 1u;
+    while (a < b) {
+        uint32_t mid = a + ((b - a) >> 1);
+        if (classify(r, key2f(mid)) >= 2) b = mid; else a = mid + 1u;
+    }
+    if (a == kmin || first > a - 1u) return false;
+    lo = key2f(first);
+    hi = key2f(a - 1u);
+    return true;
+}
+
+// One wave64 per glyph.  Lane l builds candidate record c = base + l, where
+// candidate 2s / 2s+1 are the t+ / t- roots of segment s (2s alone for a == 0);
+// survivors are compacted with a ballot + prefix popcount into the glyph's slice
+// [2*seg_start[g], ...) of the record arrays.
+__global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__ pts,
+                                                     const uint32_t *__restrict__ seg_p0,
+                                                     const uint32_t *__restrict__ glyph_seg_start,
+                                                     uint32_t n_glyphs,
+                                                     RecBounds *__restrict__ out_bounds,
+                                                     RecPayload *__restrict__ out_payload,
+                                                     uint32_t *__restrict__ glyph_rec_count)
+{
+    const uint32_t g = blockIdx.x;
+    if (g >= n_glyphs) return;
+    const uint32_t s0 = glyph_seg_start[g], s1 = glyph_seg_start[g + 1];
+    const uint32_t n_cand = 2u * (s1 - s0);
+    const uint32_t lane = threadIdx.x;
+    const size_t out_base = 2u * (size_t)s0;
+    uint32_t n_out = 0;
+    for (uint32_t base = 0; base < n_cand; base += 64u) {
+        const uint32_t c = base + lane;
+        bool valid = false;
+        RecPayload r;
+        float lo = 0.f, hi = 0.f;
+        if (c < n_cand) {
+            const uint32_t s = s0 + (c >> 1);
+            const uint32_t root = c & 1u;
+            const int16_t *p = pts + 2u * (size_t)seg_p0[s];
+            // i16 -> f32 (render_glyph.zig:43-45)
+            const float p0x = (float)p[0], p0y = (float)p[1];
+            const float p1x = (float)p[2], p1y = (float)p[3];
+            const float p2x = (float)p[4], p2y = (float)p[5];
+            const float a = p0y - 2 * p1y + p2y;                 // :48
+            r.ax = p0x - 2 * p1x + p2x;                          // :53/:65
+            r.bx = 2 * (p1x - p0x);
+            r.p0x = p0x;
+            if (a == 0.0f) {                                     // :49
+                if (root == 0u && p2y != p0y) {                  // :50
+                    r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
+                    r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
+                    valid = true;
+                }
+            } else {
+                r.a = a; r.b = p0y - p1y; r.c1 = p1y * p1y; r.c2 = p0y * p2y;    // :58, :60
+                r.flags = root ? REC_NEG_ROOT : 0u;
+                valid = true;
+            }
+            if (valid) valid = accept_interval(r, lo, hi);
+        }
+        const unsigned long long m = __ballot(valid);
+        if (valid) {
+            const uint32_t pos = n_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            out_bounds[out_base + pos] = RecBounds{lo, hi};
+            out_payload[out_base + pos] = r;
+        }
+        n_out += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) glyph_rec_count[g] = n_out;
+}
+
+void launch_prepare(const int16_t *pts, const uint32_t *seg_p0, const uint32_t *glyph_seg_start,
+                    uint32_t n_glyphs, RecBounds *out_bounds, RecPayload *out_payload,
+                    uint32_t *glyph_rec_count, hipStream_t stream)
+{
+    if (n_glyphs == 0) return;
+    hipLaunchKernelGGL(prepare_kernel, dim3(n_glyphs), dim3(64), 0, stream, pts, seg_p0,
+                       glyph_seg_start, n_glyphs, out_bounds, out_payload, glyph_rec_count);
+}
+
+}  // namespace fr

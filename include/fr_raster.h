@@ -1,0 +1,170 @@
+/*
+ * fr_raster.h — C ABI of the MI355X-native glyph rasterizer (libfr_raster.so).
+ *
+ * This is the drop-in boundary for ONE path of nyasyamorina/font-renderer: the
+ * per-pixel winding / coverage loop of src/tools/render_glyph.zig (and the
+ * TriangulatedGlyph + shader.slang + Vulkan pipeline that draws the same filled
+ * region).  The host keeps the reference's Glyph (src/font/Glyph.zig:11-24) and
+ * Image (src/tools/Image.zig:44-130) types; it hands this library flat views of
+ * the glyph's contiguous i16 points and a caller-allocated output buffer.
+ * Reference-side binding: see INTEGRATION.md and bindings/fr_raster.zig.
+ *
+ * Plain pointers and sizes only; no C++ / torch types.  All functions return an
+ * fr_status (0 = ok, < 0 = error) unless noted; fr_last_error() returns a
+ * thread-local message for the last failing call.  The library never frees or
+ * retains host pointers past a call, never aborts and never throws across the
+ * ABI.  One fr_ctx is used from one thread at a time (the reference is
+ * single-threaded: SURVEY §8b).
+ *
+ * There is NO CPU fallback: every compute entry point runs hand-written HIP
+ * kernels on a gfx950 device and fails with FR_E_HIP when none is usable.
+ */
+#ifndef FR_RASTER_H
+#define FR_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1
+
+typedef enum fr_status {
+    FR_OK = 0,
+    FR_E_INVALID = -1,      /* bad argument / malformed glyph tables               */
+    FR_E_HIP = -2,          /* HIP runtime error or no usable device               */
+    FR_E_NOMEM = -3,        /* host or device allocation failed                    */
+    FR_E_UNSUPPORTED = -4   /* valid request outside the implemented envelope      */
+} fr_status;
+
+/* What one output element holds.  The value maps are the reference's own:
+ *   FR_WINDING_I16  int16 winding number at the sample      (Image.Winding.data, Image.zig:85-88;
+ *                                                            glyphWindingAt, render_glyph.zig:35-73)
+ *   FR_GRAY_DEBUG   u8 clamp(w*20+100, 0, 255)               (render_glyph.zig:28 — what renderGlyph emits)
+ *   FR_MASK_NONZERO u8 (w != 0) ? 255 : 0                    (render_glyph.zig:29, the commented alternative)
+ *   FR_COVERAGE_U8  u8 round(255*k/n^2), k = # of the n x n sub-samples with w != 0
+ *                   (non-zero fill as :29; box filter = the MSAA average resolve,
+ *                    VulkanContext.zig:307-313 — the reference's only anti-aliasing)        */
+typedef enum fr_mode {
+    FR_WINDING_I16 = 0,
+    FR_GRAY_DEBUG = 1,
+    FR_MASK_NONZERO = 2,
+    FR_COVERAGE_U8 = 3
+} fr_mode;
+
+/* Sub-sample k of an axis sits at (k + phase)/n of a pixel:
+ *   FR_SAMPLE_CORNER phase 0   — with n = 1 exactly the reference's sample, the pixel
+ *                                *corner* (min_x + x, max_y - y) (render_glyph.zig:26-27)
+ *   FR_SAMPLE_CENTER phase 1/2 — regular n x n grid centred in the pixel              */
+typedef enum fr_sample_phase { FR_SAMPLE_CORNER = 0, FR_SAMPLE_CENTER = 1 } fr_sample_phase;
+
+typedef struct fr_raster_params {
+    int32_t mode;              /* fr_mode                                              */
+    int32_t samples_per_axis;  /* n in {1,2,4}; must be 1 unless mode = FR_COVERAGE_U8  */
+    int32_t sample_phase;      /* fr_sample_phase                                      */
+    int32_t reserved;          /* 0                                                    */
+} fr_raster_params;
+
+/* One glyph cell to rasterize.  Sample point of pixel (x, y), sub-sample (i, j):
+ *     cx = (f32(min_x + x) + (i + phase)/n) / scale
+ *     cy = (f32(max_y - y) - (j + phase)/n) / scale        (render_glyph.zig:26-27: division,
+ *                                                            y-down image, font-unit ray origin)
+ * renderGlyph's own grid is min = floor(box_min*scale), max = ceil(box_max*scale),
+ * w = max_x-min_x+1, h = max_y-min_y+1 (render_glyph.zig:13-19): fr_render_glyph_dims. */
+typedef struct fr_job {
+    uint32_t glyph;            /* index into the glyph set                             */
+    int32_t  min_x, max_y;     /* pixel coordinate of column 0 / row 0                 */
+    uint32_t w, h;             /* cell size in pixels                                  */
+    uint32_t out_x, out_y;     /* destination of the cell's (0,0) in the output, elements / rows */
+    float    scale;            /* font_size / units_per_em (render_glyph.zig:13)       */
+} fr_job;
+
+typedef struct fr_ctx fr_ctx;
+typedef struct fr_glyphset fr_glyphset;
+typedef struct fr_plan fr_plan;
+
+/* ---- library / context -------------------------------------------------- */
+int fr_abi_version(void);
+const char *fr_last_error(void);
+
+/* device: HIP device ordinal.  hip_stream: a hipStream_t to launch on (e.g. the
+ * caller's torch stream), or NULL to let the context create and own one.       */
+int fr_ctx_create(int device, void *hip_stream, fr_ctx **out);
+void fr_ctx_destroy(fr_ctx *ctx);
+int fr_ctx_sync(fr_ctx *ctx);
+/* tuning / test knobs: "kmax" (crossings kept per sample row before the exact
+ * direct-sum fallback, 1..128, default 32), "max_cols" (sample columns per strip) */
+int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
+
+/* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------
+ * points_xy      : i16 (x,y) pairs, every contour of every glyph back to back — the
+ *                  reference already keeps one glyph's points in one allocation
+ *                  (Glyph.zig:89-96), so a single glyph is passed without copying;
+ * contour_start  : n_contours+1 offsets (in points); contour c = [start[c], start[c+1]),
+ *                  even index on-curve, odd index control, last == first (Glyph.zig:23),
+ *                  so its length is odd and >= 3 (or 1: a degenerate contour, 0 curves);
+ * glyph_start    : n_glyphs+1 offsets (in contours).
+ * Uploads the points to HBM and runs the per-segment precompute kernel once
+ * (root records with exact acceptance intervals).  Scale-independent:
+ * one glyph set serves every font size, mode and sample count.                     */
+int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, const uint32_t *glyph_start, uint32_t n_glyphs,
+                       fr_glyphset **out);
+void fr_glyphset_destroy(fr_glyphset *gs);
+/* re-runs the precompute kernel on the context's stream (asynchronous); for timing */
+int fr_glyphset_prepare(fr_glyphset *gs);
+/* totals, for reporting: segments (curves) and surviving root records */
+int fr_glyphset_stats(const fr_glyphset *gs, uint64_t *n_segments, uint64_t *n_records);
+
+/* ---- batched rasterization ----------------------------------------------
+ * A plan keeps the job table resident on the device so a batch can be re-rendered
+ * without host traffic (atlas pages, benchmark steps).                              */
+int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
+                   const fr_raster_params *params, fr_plan **out);
+void fr_plan_destroy(fr_plan *plan);
+/* Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
+ * out_rows rows of out_stride elements (u8, or i16 for FR_WINDING_I16); every job
+ * must fit inside it (checked).  Pixels outside all jobs are not touched.           */
+int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows);
+/* same, bracketed by HIP events on the launch stream; synchronous; *ms = kernel time */
+int fr_plan_render_timed(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows, float *ms);
+uint64_t fr_plan_pixels(const fr_plan *plan);   /* sum of w*h over the jobs */
+
+/* One-shot: plan + render + copy back.  out_host: HOST buffer (caller-allocated,
+ * e.g. Image.Gray.data / Image.Winding.data from the Zig allocator).  Synchronous.  */
+int fr_render_batch(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
+                    const fr_raster_params *params, void *out_host, size_t out_stride, size_t out_rows);
+
+/* ---- renderGlyph drop-in (render_glyph.zig:11-33) -------------------------
+ * fr_render_glyph_dims reproduces :13-19 on the host so the caller can size the
+ * Image.Gray first; fr_render_glyph fills it: w*h u8, row-major, value per `mode`
+ * (FR_GRAY_DEBUG is what the reference's renderGlyph returns).                      */
+int fr_render_glyph_dims(const int16_t box[4], uint16_t units_per_em, uint16_t font_size,
+                         int16_t min_corner[2], int16_t max_corner[2],
+                         uint16_t *width, uint16_t *height, float *scale);
+int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                    uint32_t n_contours, const int16_t box[4], uint16_t units_per_em,
+                    uint16_t font_size, int32_t mode, void *out_host);
+
+/* ---- exact-integer path (render_glyph.zig:76-300) -------------------------
+ * fr_glyph_info_init: GlyphInfo.init (:110-146) — one CurveType (:84-95 enum order)
+ * and one include_p0 flag per curve, contours back to back, computed on the device.
+ * fr_winding_in_glyph: windingInGlyph (:160-247) at n_query integer font-unit points.
+ * fr_winding_lattice: the lattice Image.GlyphDebug.render walks (Image.zig:227-236):
+ * (x_max-x_min+3) x (y_max-y_min+3) int16, point (x_min+w-1, y_max-h+1).
+ * Predicates use 128-bit integers: identical to the reference's i64 wherever that
+ * does not overflow.                                                  */
+int fr_glyph_info_init(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, uint8_t *curve_type, uint8_t *include_p0);
+int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                        uint32_t n_contours, const int16_t *query_xy, uint32_t n_query,
+                        int16_t *out_winding);
+int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                       uint32_t n_contours, const int16_t box[4], int16_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FR_RASTER_H */

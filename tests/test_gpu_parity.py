@@ -1,0 +1,241 @@
+"""GPU suite: the HIP path (through the C ABI) against the oracle, bit for bit.
+
+Bars (BASELINE.json north_star): integer winding counts bit-exact; 8-bit coverage within
+1 LSB — these tests demand 0 LSB because every sub-sample's inside test is exact."""
+import numpy as np
+import pytest
+
+import font_renderer_amd as fr
+import oracle_lib as O
+from font_renderer_amd import render_glyph as rg
+from font_renderer_amd.atlas import atlas_shape, cell_jobs
+from font_renderer_amd.glyph import Box, Contour, Glyph, GlyphSet
+from font_renderer_amd.synth import comb_glyph, synth_glyphset
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(fr.FR_WINDING_I16, O.WINDING_I16), (fr.FR_GRAY_DEBUG, O.GRAY_DEBUG), (fr.FR_MASK_NONZERO, O.MASK_NONZERO)]
+
+
+def _batch_both(ctx, oracle, gs, jobs, mode, shape, n=1, center=False, threads=8, dgs=None):
+    own = dgs is None
+    dgs = dgs or fr.DeviceGlyphSet(ctx, gs)
+    dt = np.int16 if mode == fr.FR_WINDING_I16 else np.uint8
+    got = np.full(shape, 7, dt)
+    ref = np.full(shape, 7, dt)
+    rg.render_batch(dgs, jobs, mode, got, n, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+    oracle.render_batch(gs, jobs, mode, ref, n, center, threads)
+    if own:
+        dgs.close()
+    return got, ref
+
+
+def test_render_glyph_all_ascii_fixture(ctx, oracle, ascii_set):
+    """renderGlyph drop-in (render_glyph.zig:11-33) on all 190 real glyphs, incl. the
+    degenerate rows the reference mis-counts and the empty glyph (' ')."""
+    bad = []
+    for i in range(len(ascii_set)):
+        g, upm = ascii_set.glyph(i), int(ascii_set.g_upm[i])
+        size = (64, 33, 100, 17)[i % 4]
+        im = fr.renderGlyph(g, fr.FontInformation(upm), size, ctx=ctx)
+        want = oracle.render_glyph(g, upm, size)
+        if (im.height, im.width) != want.shape or not np.array_equal(im.as_2d(), want):
+            bad.append((i, chr(int(ascii_set.g_char[i])), size))
+    assert not bad, bad
+
+
+def test_render_glyph_stix_A_known_answer(ctx, ascii_set):
+    """SURVEY Appendix B straight from the GPU: 47x45, histogram, negatives on the y=0 row"""
+    i = ascii_set.find("STIX", "A")
+    wd = rg.renderGlyphWinding(ascii_set.glyph(i), fr.FontInformation(1000), 64, ctx=ctx)
+    assert (wd.width, wd.height) == (47, 45)
+    hist = {int(v): int(c) for v, c in zip(*np.unique(wd.data, return_counts=True))}
+    assert hist == {-2: 1, -1: 28, 0: 1641, 1: 445}
+    assert set(np.nonzero(wd.as_2d() < 0)[0].tolist()) == {44}
+
+
+@pytest.mark.parametrize("mode,omode", MODES)
+def test_modes_atlas_ascii(ctx, oracle, ascii_set, mode, omode):
+    """configs[1] shape: 95 glyphs, 128x128 cells, one 2048^2 atlas (n = 1 modes)"""
+    gs = ascii_set.gs
+    jobs = cell_jobs(gs, 128, 100, ascii_set.g_upm, 16, first_glyph=0, n_glyphs=95)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (2048, 2048))
+    assert np.array_equal(got, ref)
+    assert (got[6 * 128:, :] == 7).all()        # cells beyond the 95th are not touched
+
+
+@pytest.mark.parametrize("n,center", [(1, False), (1, True), (2, False), (2, True), (4, False), (4, True)])
+def test_coverage_atlas_ascii(ctx, oracle, ascii_set, n, center):
+    gs = ascii_set.gs
+    jobs = cell_jobs(gs, 64, 50, ascii_set.g_upm, 16, first_glyph=95, n_glyphs=95)   # DejaVuSerif-Italic
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, (6 * 64, 16 * 64), n, center)
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    assert diff.max() == 0, f"max |coverage error| = {diff.max()} LSB at {np.argwhere(diff > 0)[:5].tolist()}"
+
+
+@pytest.mark.parametrize("segs,cell", [(16, 64), (32, 128), (64, 96), (128, 256), (256, 128)])
+def test_coverage_synthetic(ctx, oracle, segs, cell):
+    """SURVEY §8d synthetic outlines, 4x4 centre samples (configs[2]/[3] shapes, reduced count)"""
+    n_g = 8 if cell < 200 else 4
+    gs = synth_glyphset(n_g, segs, first_index=100 + segs)
+    jobs = cell_jobs(gs, cell, cell, 2048, 4)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(n_g, cell, 4), 4, True)
+    assert np.array_equal(got, ref)
+    assert 0.05 < (ref > 0).mean() < 0.95
+
+
+def test_ragged_cells_unaligned_output(ctx, oracle, ascii_set):
+    """odd sizes, unaligned destinations, a stride that is not a multiple of 16"""
+    gs = ascii_set.gs
+    rows = []
+    rng = np.random.default_rng(3)
+    x = 1
+    for k, gi in enumerate(rng.integers(0, len(ascii_set), 12)):
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+        s = np.float32(rng.integers(8, 120)) / np.float32(ascii_set.g_upm[gi])
+        rows.append((int(gi), int(rng.integers(-20, 5)), int(rng.integers(20, 90)), w, h, x, int(rng.integers(0, 9)), s))
+        x += w + int(rng.integers(0, 3))
+    jobs = rg.make_jobs(rows)
+    for mode, omode in MODES + [(fr.FR_COVERAGE_U8, O.COVERAGE_U8)]:
+        n = 4 if mode == fr.FR_COVERAGE_U8 else 1
+        got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (311, x + 5), n, mode == fr.FR_COVERAGE_U8)
+        assert np.array_equal(got, ref), mode
+
+
+def test_overfull_rows_take_the_exact_fallback(ctx, oracle):
+    """a comb with 40 teeth: 80 crossings per ray > kmax -> direct-sum fallback; also kmax = 2"""
+    cs, box = comb_glyph(40)
+    g = Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs])
+    gs = GlyphSet([g])
+    jobs = cell_jobs(gs, 192, 180, 2048, 1)
+    try:
+        for kmax in (32, 2, 1):
+            ctx.set_option("kmax", kmax)
+            for mode, n in [(fr.FR_COVERAGE_U8, 4), (fr.FR_WINDING_I16, 1), (fr.FR_COVERAGE_U8, 2)]:
+                got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (192, 192), n, True)
+                assert np.array_equal(got, ref), (kmax, mode, n)
+        ctx.set_option("kmax", 3)
+        sg = synth_glyphset(6, 48, first_index=900)
+        sj = cell_jobs(sg, 80, 80, 2048, 3)
+        got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_COVERAGE_U8, atlas_shape(6, 80, 3), 4, True)
+        assert np.array_equal(got, ref)
+    finally:
+        ctx.set_option("kmax", 32)
+
+
+def test_wide_cells_are_split_into_strips(ctx, oracle, ascii_set):
+    """a 700-pixel-wide render needs 2800 sample columns > max_cols: column strips"""
+    i = ascii_set.find("DejaVu", "W")
+    g, upm = ascii_set.glyph(i), int(ascii_set.g_upm[i])
+    gs = GlyphSet([g])
+    try:
+        for max_cols in (2048, 256):
+            ctx.set_option("max_cols", max_cols)
+            jobs = cell_jobs(gs, 700, 600, upm, 1)
+            jobs["h"] = 90
+            jobs["max_y"] -= 200
+            got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, (90, 700), 4, True)
+            assert np.array_equal(got, ref), max_cols
+            got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_GRAY_DEBUG, (90, 700))
+            assert np.array_equal(got, ref), max_cols
+    finally:
+        ctx.set_option("max_cols", 2048)
+
+
+def test_edge_cases(ctx, oracle):
+    # empty glyph: 1x1 image of value 100 (render_glyph.zig:14-22 with a zero box)
+    im = fr.renderGlyph(Glyph.initEmpty(), fr.FontInformation(1000), 64, ctx=ctx)
+    assert (im.width, im.height) == (1, 1) and im.data[0] == 100
+    # a contour of one point has no curves (len/2 == 0, render_glyph.zig:38)
+    g = Glyph(Box(0, 0, 10, 10), [Contour(np.array([[5, 5]], np.int16))])
+    assert np.array_equal(fr.renderGlyph(g, fr.FontInformation(100), 50, ctx=ctx).as_2d(), oracle.render_glyph(g, 100, 50))
+    # horizontal / vertical edges through sample rows, double roots, coincident control points
+    pts = np.array([[0, 0], [0, 50], [0, 100], [50, 100], [100, 100], [100, 50], [100, 0], [50, 0], [0, 0]], np.int16)
+    sq = Glyph(Box(0, 0, 100, 100), [Contour(pts)])
+    for size in (100, 50, 7):
+        assert np.array_equal(fr.renderGlyph(sq, fr.FontInformation(100), size, ctx=ctx).as_2d(), oracle.render_glyph(sq, 100, size))
+    arch = Glyph(Box(0, 0, 200, 100), [Contour(np.array([[0, 0], [100, 200], [200, 0], [100, 0], [0, 0]], np.int16))])
+    for size in (200, 64):   # rows tangent to the apex: delta == 0, the double root counted twice
+        assert np.array_equal(fr.renderGlyph(arch, fr.FontInformation(200), size, ctx=ctx).as_2d(), oracle.render_glyph(arch, 200, size))
+    # extreme coordinates of the i16 domain
+    big = Glyph(Box(-32000, -32000, 32000, 32000), [Contour(np.array(
+        [[-32000, -32000], [-32000, 0], [-32000, 32000], [0, 31000], [32000, 32000], [31000, 0], [32000, -32000], [0, -31000], [-32000, -32000]], np.int16))])
+    assert np.array_equal(fr.renderGlyph(big, fr.FontInformation(64000), 97, ctx=ctx).as_2d(), oracle.render_glyph(big, 64000, 97))
+    # no jobs / bad arguments
+    dgs = fr.DeviceGlyphSet(ctx, GlyphSet([sq]))
+    with pytest.raises(fr.FrError):
+        rg.render_batch(dgs, rg.make_jobs([(5, 0, 0, 4, 4, 0, 0, 1.0)]), fr.FR_GRAY_DEBUG, np.zeros((4, 4), np.uint8))
+    with pytest.raises(fr.FrError):
+        rg.render_batch(dgs, rg.make_jobs([(0, 0, 0, 8, 8, 0, 0, 1.0)]), fr.FR_GRAY_DEBUG, np.zeros((4, 4), np.uint8))
+    with pytest.raises(fr.FrError):
+        fr.DeviceGlyphSet(ctx, GlyphSet.from_arrays(np.zeros((4, 2), np.int16), [0, 4], [0, 1], [[0, 0, 1, 1]]))   # even length
+    dgs.close()
+
+
+def test_random_scales_and_offsets_property(ctx, oracle):
+    """many (scale, origin) pairs on one synthetic glyph: rows landing exactly on vertices etc."""
+    gs = synth_glyphset(1, 40, first_index=4242)
+    rng = np.random.default_rng(11)
+    rows, y = [], 0
+    for k in range(24):
+        s = np.float32(rng.integers(3, 400)) / np.float32(2048)
+        rows.append((0, int(rng.integers(-3, 40)), int(rng.integers(10, 400)), 48, 40, (k % 6) * 48, (k // 6) * 40, s))
+    jobs = rg.make_jobs(rows)
+    for mode in (fr.FR_WINDING_I16, fr.FR_COVERAGE_U8):
+        got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (160, 288), 4 if mode == fr.FR_COVERAGE_U8 else 1, False)
+        assert np.array_equal(got, ref)
+
+
+def test_exact_integer_path(ctx, oracle, ascii_set):
+    """GlyphInfo.init + windingInGlyph (render_glyph.zig:76-300) incl. the GlyphDebug lattice"""
+    oracle.diag_reset()
+    for font, ch in [("STIX", "A"), ("STIX", "g"), ("DejaVu", "S"), ("DejaVu", "8"), ("STIX", "@")]:
+        g = ascii_set.glyph(ascii_set.find(font, ch))
+        info = fr.GlyphInfo.init(g, ctx=ctx)
+        ct, ip = oracle.glyph_info(g)
+        assert np.array_equal(info.curve_type, ct) and np.array_equal(info.include_p0, ip)
+        assert np.array_equal(fr.winding_lattice(g, ctx=ctx), oracle.winding_lattice(g)), (font, ch)
+    g = ascii_set.glyph(ascii_set.find("STIX", "A"))
+    q = np.array([(420, 321), (14, 0), (360, 674), (100, 0), (-5, -5)], np.int16)
+    assert np.array_equal(fr.windingInGlyph(g, None, q, ctx=ctx), oracle.winding_in_glyph(g, q))
+    assert fr.windingInGlyph(g, None, (420, 321), ctx=ctx) == 0
+    assert oracle.diag()[0] == 0          # fixtures stay inside the reference's i64 domain
+    # synthetic long curves: beyond i64 the reference is undefined; both sides use 128-bit
+    gs = synth_glyphset(1, 24, first_index=77)
+    gg = gs.glyph(0)
+    qq = np.stack(np.meshgrid(np.arange(60, 2000, 37), np.arange(60, 2000, 41)), -1).reshape(-1, 2).astype(np.int16)
+    assert np.array_equal(fr.windingInGlyph(gg, None, qq, ctx=ctx), oracle.winding_in_glyph(gg, qq))
+
+
+def test_full_size_properties_config3_shape(ctx):
+    """BASELINE configs[2] shape at reduced count (512 glyphs x 256^2, S = 128, 16 samples):
+    size-independent properties instead of the oracle — sharded == unsharded byte for byte
+    (SURVEY §4 item 5), idempotent re-render, n=1 coverage == mask, untouched background."""
+    import torch
+    gs = synth_glyphset(512, 128)
+    cols, cell = 16, 256
+    H, W = atlas_shape(512, cell, cols)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    jobs = cell_jobs(gs, cell, cell, 2048, cols)
+    out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    plan.render(out.data_ptr(), W, H); ctx.sync()
+    a = out.cpu().numpy().copy()
+    plan.render(out.data_ptr(), W, H); ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), a)                     # idempotent
+    assert plan.pixels == 512 * cell * cell
+    # "fake cluster": 8 shards rendered one after another into their own row bands
+    from font_renderer_amd.shard import shard_ranges
+    out2 = torch.zeros_like(out)
+    for lo, hi in shard_ranges(512, 8):
+        sub = gs.subset(lo, hi)
+        sd = fr.DeviceGlyphSet(ctx, sub)
+        sj = cell_jobs(sub, cell, cell, 2048, cols)
+        band = out2[(lo // cols) * cell:]
+        sp = fr.Plan(sd, sj, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        sp.render(band.data_ptr(), W, band.shape[0]); ctx.sync()
+        sp.close(); sd.close()
+    assert np.array_equal(out2.cpu().numpy(), a)
+    frac = (a > 0).mean()
+    assert 0.2 < frac < 0.8
+    plan.close(); dgs.close()
