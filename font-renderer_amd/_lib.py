@@ -64,6 +64,29 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so.7; if this library pulled in /opt/rocm's copy first, a later
+    `import torch` would bring a second runtime into the process (observed: "No HIP GPUs
+    are available" + a crash at exit).  So when torch is installed, its runtime is loaded
+    first and libfr_raster.so binds to it by SONAME.  FR_HIP_RUNTIME=system skips this
+    (pure C / Zig hosts never see torch and use /opt/rocm's runtime via RUNPATH)."""
+    if os.environ.get("FR_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library() -> C.CDLL:
     """dlopen libfr_raster.so (built by __graft_entry__.build()); raises if absent."""
     global _lib
@@ -74,6 +97,7 @@ def load_library() -> C.CDLL:
         raise FileNotFoundError(
             f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
