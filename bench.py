@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--glyphs", type=int, default=0, help="override glyph count (smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--kmax", type=int, default=0, help="crossings per sample row kept in registers (8/16/32)")
     ap.add_argument("--no-prep-in-step", action="store_true", help="time the render kernel alone per step")
     args = ap.parse_args()
 
@@ -72,6 +73,8 @@ def main():
     H, W = atlas_shape(G, cell, cols)
     stream = torch.cuda.Stream()
     ctx = fr.Context(local, stream.cuda_stream)
+    if args.kmax:
+        ctx.set_option("kmax", args.kmax)
     with torch.cuda.stream(stream):
         out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     dgs = fr.DeviceGlyphSet(ctx, gs)                       # points -> HBM (+ first precompute)

@@ -18,7 +18,6 @@ namespace fr {
 void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, RecBounds *,
                     RecPayload *, uint32_t *, hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
-size_t render_lds_bytes(uint32_t strip_w, int n, uint32_t kmax);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
                        uint8_t *, hipStream_t);
 void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
@@ -52,8 +51,8 @@ struct fr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    uint32_t kmax = 32;          // crossings kept per sample row before the direct-sum fallback
-    uint32_t max_cols = 2048;    // sample columns per strip (LDS table of cx)
+    uint32_t kmax = 16;          // crossings kept per sample row (register array: 8, 16 or 32) before the direct-sum fallback
+    uint32_t strip_px = 256;     // column strip width, pixels (multiple of 16, <= 256)
 };
 
 struct fr_glyphset {
@@ -133,9 +132,9 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
         ctx->kmax = (uint32_t)value;
         return FR_OK;
     }
-    if (!strcmp(key, "max_cols")) {
-        if (value < 64 || value > 8192 || (value % 64)) return fail(FR_E_INVALID, "max_cols must be a multiple of 64 in [64,8192]");
-        ctx->max_cols = (uint32_t)value;
+    if (!strcmp(key, "strip_px")) {
+        if (value < 16 || value > 256 || (value % 16)) return fail(FR_E_INVALID, "strip_px must be a multiple of 16 in [16,256]");
+        ctx->strip_px = (uint32_t)value;
         return FR_OK;
     }
     return fail(FR_E_INVALID, "fr_ctx_set_option: unknown key '%s'", key);
@@ -324,7 +323,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     p->ctx = ctx; p->gs = gs; p->n_jobs = n_jobs; p->params = *params;
     p->pixels = pixels; p->need_cols = need_cols; p->need_rows = need_rows;
     const uint32_t band = 256u / n;
-    const uint32_t cap_w = (ctx->max_cols / n) & ~15u;                  // strip width cap, pixels
+    const uint32_t cap_w = ctx->strip_px;                               // strip width cap, pixels
     uint32_t sw = (max_w + 15u) & ~15u;
     if (sw > cap_w) sw = cap_w;
     if (sw == 0) sw = 16;
@@ -371,6 +370,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
+    a.nwin_log = 0; a.lds_tail = 0;
     HIP_TRY(hipSetDevice(plan->ctx->device));
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;

@@ -58,6 +58,7 @@ struct RenderArgs {
     uint64_t out_stride;               // elements
     uint32_t n_jobs, bands, strips, strip_w, kmax;
     int32_t phase_center;
+    uint32_t nwin_log, lds_tail;       // filled by launch_render (LDS plan)
 };
 
 // order-preserving map binary32 -> u32 (total order, -0 < +0)

@@ -7,20 +7,27 @@
 //
 //   winding(cx, cy) = sum over accepted roots k of  sign_k * [ not (xx_k < cx) ]   (:54,:66)
 //
-// where (xx_k, sign_k) depend only on the segment and the ROW (cy).  So, per
-// workgroup = (cell, band of 256/N pixel rows, column strip):
-//   phase 0  stage the glyph's root records whose exact acceptance interval
-//            [lo, hi] (fr_prepare.hip) meets the band into LDS — wave64 ballot +
-//            prefix-popcount compaction;
-//   phase 1  one lane per sample ROW: for each staged record with lo <= cy <= hi
-//            evaluate t, xx, sign in the reference's own f32 operation order, turn
-//            xx into J = #{sample columns j : cx(j) <= xx} against an LDS table of the
-//            exact cx(j) (cx is monotone in j), sort the row's few crossings by J and
-//            suffix-sum the signs -> breakpoints (b_i, winding on [b_{i-1}, b_i));
-//   phase 2  one lane per 16-pixel window: spans -> sample bitmasks -> popcounts ->
-//            16 output bytes in one coalesced 16-B store per lane (128 B per row run).
-// Per-pixel work is O(crossings of its row), not O(segments).  Rows with more than
-// `kmax` crossings fall back to the direct sum over records (same integers).
+// where (xx_k, sign_k) depend only on the segment and the ROW (cy).  Per workgroup =
+// (cell, band of 256/N pixel rows, column strip), 4 waves:
+//   phase 0  stage the glyph's root records whose exact acceptance interval [lo, hi]
+//            (fr_prepare.hip) meets the band into LDS — wave64 ballot + prefix-popcount
+//            compaction;
+//   phase 1  one lane per sample ROW.  Each wave pulls 64 staged records into registers
+//            (one per lane) and walks them with v_readlane broadcasts — no LDS round trip
+//            per record.  A lane whose cy lies in [lo, hi] evaluates t, xx, sign in the
+//            reference's own f32 operation order, converts xx into
+//            J = #{sample columns j : cx(j) <= xx} against an LDS table of the exact cx(j)
+//            (cx is monotone in j), and inserts (J, sign) into a small SORTED array kept
+//            in registers (min/max compare-exchange chain);
+//   phase 1b the lane suffix-sums its signs from the right: crossing i TOGGLES
+//            inside/outside iff the running winding changes between zero and non-zero
+//            across it.  Each toggle at column t XORs a prefix mask into the 64-bit LDS
+//            word of the 16-pixel window holding t (ds_xor_b64) and flips a per-row
+//            "windows to the left are filled" parity word — O(toggles) per row;
+//   phase 2  one lane per 16-pixel window: N mask words -> SWAR popcount per pixel ->
+//            16 output bytes, one coalesced 16-B store per lane (256 B per row run).
+// Per-pixel work is O(crossings of its row), not O(segments).  A row with more than CAP
+// crossings falls back to the direct sum over records (same integers, slower).
 #include "fr_device.hpp"
 
 namespace fr {
@@ -44,17 +51,37 @@ __device__ __noinline__ int brute_winding(const RecBounds *__restrict__ bounds,
     return w;
 }
 
-__device__ __forceinline__ uint8_t gray_debug(int w)
+__device__ __forceinline__ uint32_t gray_debug(int w)
 {
     int v = w * 20 + 100;                       // render_glyph.zig:28
-    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-template <int MODE, int N>
+struct __attribute__((aligned(16))) RecLds {    // 48 B: bounds + payload, one per lane in phase 1
+    float lo, hi, a, b, c1, c2, ax, bx, p0x;
+    uint32_t flags, pad0, pad1;
+};
+
+__device__ __forceinline__ float bcast(float v, uint32_t k)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)k));
+}
+
+constexpr uint32_t EMPTY = 0xffffffffu;
+
+// LDS line of sample row r in the window-mask array.  Swapping line parity with bit 2
+// puts rows r and r+4 (the same sub-row of two adjacent pixel rows, read together by one
+// ds_read_b64 in phase 2) into different 128-B halves of the 256-B bank space.
+__device__ __forceinline__ uint32_t mask_line(uint32_t r) { return r ^ ((r >> 2) & 1u); }
+
+template <int MODE, int N, int CAP>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
     constexpr uint32_t BAND = 256u / N;         // pixel rows per workgroup
-    constexpr int WCOLS = 16 * N;               // sample columns per 16-pixel window
+    constexpr int WCOLS = 16 * N;               // sample columns per 16-pixel window (<= 64)
+    constexpr int WSHIFT = (N == 4) ? 6 : (N == 2 ? 5 : 4);
+    constexpr unsigned long long WALL = (N == 4) ? ~0ull : ((1ull << WCOLS) - 1ull);
+    constexpr bool COV = (MODE == MODE_COVERAGE_U8);
     extern __shared__ __align__(16) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -69,20 +96,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const uint32_t sw = min(A.strip_w, job.w - x0s);            // strip width, pixels
     const uint32_t ncol = sw * N;                               // sample columns in the strip
     const uint32_t nrows = band_rows * N;                       // sample rows in the band
-    const uint32_t kmax = A.kmax;
     const int phase = A.phase_center;
+    const uint32_t nwin_log = A.nwin_log;                       // windows per row, padded to 2^k
+    const uint32_t nwin_pad = 1u << nwin_log;
 
+    // LDS: [cx table | staged records] are dead once phase 1 ends; the window masks
+    // (coverage) or breakpoint rows (winding modes) of phase 1b/2 reuse the same bytes.
     float *s_cx = reinterpret_cast<float *>(smem);
-    RecBounds *s_recb = reinterpret_cast<RecBounds *>(s_cx + (size_t)A.strip_w * N);
-    RecPayload *s_recp = reinterpret_cast<RecPayload *>(s_recb + 256);
-    uint32_t *s_list = reinterpret_cast<uint32_t *>(s_recp + 256);   // [kmax][256]
-    uint32_t *s_meta = s_list + (size_t)kmax * 256u;                 // [256] first | cnt<<8 | ovf<<16
-    uint32_t *s_nact = s_meta + 256;
+    RecLds *s_rec = reinterpret_cast<RecLds *>(s_cx + (size_t)A.strip_w * N);
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(smem);   // [256][nwin_pad]
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(smem);                        // [256][CAP]
+    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail);          // [256]
+    uint32_t *s_nact = s_fill + 256;
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
-    for (uint32_t j = tid; j < ncol; j += 256u)
-        s_cx[j] = ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
+    auto col_cx = [&](uint32_t j) -> float {
+        return ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
+    };
+    for (uint32_t j = tid; j < ncol; j += 256u) s_cx[j] = col_cx(j);
 
     // ray height of sample row r of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
     auto row_cy = [&](uint32_t r) -> float {
@@ -103,7 +135,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const float jscale = job.scale * (float)N;
     const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
 
-    uint32_t cnt = 0;
+    uint32_t e[CAP];                            // sorted ascending: (J << 16) | (sign & 0xffff)
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) e[i] = EMPTY;
+    bool ovf = false;
+
     for (uint32_t base = 0; base < rec_cnt; base += 256u) {
         if (tid == 0) *s_nact = 0;
         __syncthreads();
@@ -121,18 +157,28 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         wbase = __shfl(wbase, 0);
         if (act) {
             const uint32_t idx = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            s_recb[idx] = b;
-            s_recp[idx] = gp[c];
+            const RecPayload p = gp[c];
+            RecLds r;
+            r.lo = b.lo; r.hi = b.hi; r.a = p.a; r.b = p.b; r.c1 = p.c1; r.c2 = p.c2;
+            r.ax = p.ax; r.bx = p.bx; r.p0x = p.p0x; r.flags = p.flags; r.pad0 = 0; r.pad1 = 0;
+            s_rec[idx] = r;
         }
         __syncthreads();
-        const uint32_t nact = *s_nact;
-        // ---- phase 1: crossings of my sample row
-        if (row_valid) {
-            for (uint32_t k = 0; k < nact; ++k) {
-                const RecBounds rb = s_recb[k];
-                if (cy >= rb.lo && cy <= rb.hi) {
+        const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_nact);
+        // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane
+        for (uint32_t cb = 0; cb < nact; cb += 64u) {
+            const RecLds mine = s_rec[min(cb + lane, nact - 1u)];
+            const uint32_t cn = min(64u, nact - cb);
+            for (uint32_t k = 0; k < cn; ++k) {
+                const float lo = bcast(mine.lo, k), hi = bcast(mine.hi, k);
+                if (row_valid && cy >= lo && cy <= hi) {
+                    RecPayload r;
+                    r.a = bcast(mine.a, k); r.b = bcast(mine.b, k); r.c1 = bcast(mine.c1, k);
+                    r.c2 = bcast(mine.c2, k); r.ax = bcast(mine.ax, k); r.bx = bcast(mine.bx, k);
+                    r.p0x = bcast(mine.p0x, k);
+                    r.flags = (uint32_t)__builtin_amdgcn_readlane((int)mine.flags, (int)k);
                     float xx; int sgn;
-                    rec_cross(s_recp[k], cy, xx, sgn);
+                    rec_cross(r, cy, xx, sgn);
                     // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
                     float gf = xx * jscale - joff;
                     gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
@@ -140,147 +186,114 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     while (J < (int)ncol && s_cx[J] <= xx) ++J;
                     while (J > 0 && s_cx[J - 1] > xx) --J;
                     if (J > 0) {
-                        if (cnt < kmax) s_list[cnt * 256u + tid] = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
-                        ++cnt;
+                        uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
+#pragma unroll
+                        for (int i = 0; i < CAP; ++i) {     // sorted insert, registers only
+                            const uint32_t mn = min(e[i], x);
+                            x = max(e[i], x);
+                            e[i] = mn;
+                        }
+                        if (x != EMPTY) ovf = true;
                     }
                 }
             }
         }
         __syncthreads();
     }
+    if (rec_cnt == 0) __syncthreads();          // the cx-table writes above vs. the reuse below
 
-    // ---- sort my row's crossings by J, suffix-sum the signs into breakpoints
-    {
-        const bool ovf = cnt > kmax;
-        uint32_t first = 0;
-        if (!ovf && cnt > 0) {
-            for (uint32_t i = 1; i < cnt; ++i) {
-                const uint32_t e = s_list[i * 256u + tid];
-                int j = (int)i - 1;
-                while (j >= 0 && (s_list[(uint32_t)j * 256u + tid] >> 16) > (e >> 16)) {
-                    s_list[(uint32_t)(j + 1) * 256u + tid] = s_list[(uint32_t)j * 256u + tid];
-                    --j;
-                }
-                s_list[(uint32_t)(j + 1) * 256u + tid] = e;
-            }
-            uint32_t mpos = cnt;
-            int run = 0;
-            for (int i = (int)cnt - 1; i >= 0; --i) {
-                const uint32_t e = s_list[(uint32_t)i * 256u + tid];
-                run += (int)(int16_t)(e & 0xffffu);
-                const uint32_t Jb = e >> 16;
-                if (i == 0 || (s_list[(uint32_t)(i - 1) * 256u + tid] >> 16) != Jb) {
-                    --mpos;
-                    s_list[mpos * 256u + tid] = (Jb << 16) | ((uint32_t)run & 0xffffu);
-                }
-            }
-            first = mpos;
-        }
-        s_meta[tid] = first | ((ovf ? 0u : cnt) << 8) | ((ovf ? 1u : 0u) << 16);
-    }
-    __syncthreads();
+    const size_t out_row0 = (size_t)job.out_y + y0;
+    const size_t out_col0 = (size_t)job.out_x + x0s;
 
-    // ---- phase 2: 16-pixel windows
-    const uint32_t nwin = (sw + 15u) / 16u;
-    const size_t esz = (MODE == MODE_WINDING_I16) ? 2 : 1;
-    for (uint32_t win = tid; win < band_rows * nwin; win += 256u) {
-        const uint32_t yl = win / nwin, wx = win % nwin;
-        const uint32_t px0 = wx * 16u;                          // first pixel of the window in the strip
-        const int j0 = (int)(px0 * N);
-        const uint32_t nvalid = min(16u, sw - px0);
-        const size_t eidx = ((size_t)job.out_y + y0 + yl) * A.out_stride + job.out_x + x0s + px0;
-
-        if (MODE == MODE_COVERAGE_U8) {
-            uint32_t k[16];
+    if (COV) {
+        // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity (register)
+        {
+            unsigned long long *line = s_mask + ((size_t)mask_line(tid) << nwin_log);
+            for (uint32_t wv = 0; wv < nwin_pad; ++wv) line[wv] = 0ull;
+            uint32_t fill = 0;
+            if (!ovf) {
+                int run = 0;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) k[p] = 0;
-#pragma unroll
-            for (int rr = 0; rr < N; ++rr) {
-                const uint32_t r = yl * N + rr;
-                const uint32_t meta = s_meta[r];
-                unsigned long long mask = 0;
-                if (meta >> 16) {
-                    const float cyr = row_cy(r);
-                    for (int cidx = 0; cidx < WCOLS; ++cidx) {
-                        const int j = j0 + cidx;
-                        if (j < (int)ncol && brute_winding(gb, gp, rec_cnt, s_cx[j], cyr) != 0)
-                            mask |= 1ull << cidx;
-                    }
-                } else {
-                    const uint32_t fst = meta & 0xffu, ecnt = (meta >> 8) & 0xffu;
-                    int prev = 0;
-                    for (uint32_t i = fst; i < ecnt; ++i) {
-                        const uint32_t e = s_list[i * 256u + r];
-                        const int bq = (int)(e >> 16);
-                        if ((e & 0xffffu) != 0u) {
-                            const int lo = max(prev - j0, 0), hi = min(bq - j0, WCOLS);
-                            if (hi > lo) mask |= ((~0ull) >> (64 - (hi - lo))) << lo;
+                for (int i = CAP - 1; i >= 0; --i) {
+                    if (e[i] != EMPTY) {
+                        const int before = run;
+                        run += (int)(int16_t)(e[i] & 0xffffu);
+                        if ((run != 0) != (before != 0)) {
+                            const uint32_t t = e[i] >> 16;                  // 1 .. ncol
+                            const uint32_t wv = (t - 1u) >> WSHIFT;
+                            const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
+                            atomicXor(line + wv, ~0ull >> (64u - cb));
+                            fill ^= (1u << wv) - 1u;                        // every window to the left flips
                         }
-                        prev = bq;
                     }
                 }
-#pragma unroll
-                for (int p = 0; p < 16; ++p)
-                    k[p] += (uint32_t)__popc((uint32_t)(mask >> (p * N)) & ((1u << N) - 1u));
+            } else if (row_valid) {
+                // over-full row: direct sum per sample column (same integers, slow path)
+                for (uint32_t wv = 0; wv < nwin_pad; ++wv) {
+                    unsigned long long mk = 0;
+                    for (int cidx = 0; cidx < WCOLS; ++cidx) {
+                        const uint32_t j = (wv << WSHIFT) + (uint32_t)cidx;
+                        if (j < ncol && brute_winding(gb, gp, rec_cnt, col_cx(j), cy) != 0) mk |= 1ull << cidx;
+                    }
+                    line[wv] = mk;
+                }
             }
-            uint32_t pk[4] = {0, 0, 0, 0};
+            s_fill[tid] = fill;
+        }
+        __syncthreads();
+
+        // ---- phase 2: one lane per 16-pixel window
+        const uint32_t wx = tid & (nwin_pad - 1u);
+        const uint32_t px0 = wx * 16u;
+        if (px0 < sw) {
+            const uint32_t nvalid = min(16u, sw - px0);
+            for (uint32_t yl = tid >> nwin_log; yl < band_rows; yl += (256u >> nwin_log)) {
+                unsigned long long mask[N];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const uint32_t v = (2u * 255u * k[p] + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
-                pk[p >> 2] |= v << (8 * (p & 3));
-            }
-            uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
-            if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            } else {
-                for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
-            }
-        } else {
-            // N == 1: one sample per pixel, winding value needed
-            int w[16];
+                for (int rr = 0; rr < N; ++rr) {
+                    const uint32_t r = yl * N + rr;
+                    const unsigned long long mk = s_mask[((size_t)mask_line(r) << nwin_log) + wx];
+                    mask[rr] = mk ^ (((s_fill[r] >> wx) & 1u) ? WALL : 0ull);
+                }
+                uint32_t pk[4];
+                if (N == 4) {
+                    // SWAR: per-nibble popcounts of the 4 sample rows, summed per pixel
+                    unsigned long long s01 = 0, s23 = 0;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) w[p] = 0;
-            const uint32_t r = yl;
-            const uint32_t meta = s_meta[r];
-            if (meta >> 16) {
-                const float cyr = row_cy(r);
-                for (uint32_t p = 0; p < nvalid; ++p)
-                    w[p] = brute_winding(gb, gp, rec_cnt, s_cx[j0 + (int)p], cyr);
-            } else {
-                const uint32_t fst = meta & 0xffu, ecnt = (meta >> 8) & 0xffu;
-                int prev = 0;
-                for (uint32_t i = fst; i < ecnt; ++i) {
-                    const uint32_t e = s_list[i * 256u + r];
-                    const int bq = (int)(e >> 16);
-                    const int v = (int)(int16_t)(e & 0xffffu);
+                    for (int rr = 0; rr < 4; ++rr) {
+                        unsigned long long x = mask[rr];
+                        x = x - ((x >> 1) & 0x5555555555555555ull);
+                        x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+                        if (rr < 2) s01 += x; else s23 += x;
+                    }
+                    const unsigned long long M = 0x0f0f0f0f0f0f0f0full;
+                    const unsigned long long ke = (s01 & M) + (s23 & M);                 // even pixels, 0..16
+                    const unsigned long long ko = ((s01 >> 4) & M) + ((s23 >> 4) & M);   // odd pixels
+                    // round_half_up(255*k/16) = 16k - (k > 8), per byte, in independent 32-bit halves
+                    uint32_t ve[2], vo[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const uint32_t a = (uint32_t)(ke >> (32 * hlf)), b2 = (uint32_t)(ko >> (32 * hlf));
+                        ve[hlf] = (a << 4) - (((a + 0x07070707u) >> 4) & 0x01010101u);
+                        vo[hlf] = (b2 << 4) - (((b2 + 0x07070707u) >> 4) & 0x01010101u);
+                    }
+                    pk[0] = __builtin_amdgcn_perm(vo[0], ve[0], 0x05010400u);
+                    pk[1] = __builtin_amdgcn_perm(vo[0], ve[0], 0x07030602u);
+                    pk[2] = __builtin_amdgcn_perm(vo[1], ve[1], 0x05010400u);
+                    pk[3] = __builtin_amdgcn_perm(vo[1], ve[1], 0x07030602u);
+                } else {
+                    pk[0] = pk[1] = pk[2] = pk[3] = 0;
 #pragma unroll
                     for (int p = 0; p < 16; ++p) {
-                        const int j = j0 + p;
-                        if (j >= prev && j < bq) w[p] = v;
+                        uint32_t k = 0;
+#pragma unroll
+                        for (int rr = 0; rr < N; ++rr)
+                            k += (uint32_t)__popc((uint32_t)(mask[rr] >> (p * N)) & ((1u << N) - 1u));
+                        const uint32_t v = (2u * 255u * k + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
+                        pk[p >> 2] |= v << (8 * (p & 3));
                     }
-                    prev = bq;
                 }
-            }
-            if (MODE == MODE_WINDING_I16) {
-                int16_t *dst = reinterpret_cast<int16_t *>(A.out) + eidx;
-                if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
-                    uint32_t pk[8];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p)
-                        pk[p] = ((uint32_t)w[2 * p] & 0xffffu) | ((uint32_t)w[2 * p + 1] << 16);
-                    reinterpret_cast<uint4 *>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                    reinterpret_cast<uint4 *>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                } else {
-                    for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (int16_t)w[p];
-                }
-            } else {
-                uint32_t pk[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    const uint32_t v = (MODE == MODE_GRAY_DEBUG) ? gray_debug(w[p]) : (w[p] != 0 ? 255u : 0u);
-                    pk[p >> 2] |= v << (8 * (p & 3));
-                }
-                uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
+                uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + (out_row0 + yl) * A.out_stride + out_col0 + px0;
                 if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
                     *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 } else {
@@ -288,20 +301,100 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 }
             }
         }
+    } else {
+        // ---- winding-value modes (N == 1): breakpoints (b_i, winding on [b_{i-1}, b_i)) per row
+        {
+            uint32_t *dst = s_row + tid * CAP;
+            int run = 0;
+#pragma unroll
+            for (int i = CAP - 1; i >= 0; --i) {
+                const bool have = e[i] != EMPTY;
+                if (have) run += (int)(int16_t)(e[i] & 0xffffu);
+                dst[i] = have ? ((e[i] & 0xffff0000u) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
+            }
+            if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
+        }
+        __syncthreads();
+        const uint32_t wx = tid & (nwin_pad - 1u);
+        const uint32_t px0 = wx * 16u;
+        if (px0 < sw) {
+            const uint32_t nvalid = min(16u, sw - px0);
+            const int j0 = (int)px0;
+            for (uint32_t yl = tid >> nwin_log; yl < band_rows; yl += (256u >> nwin_log)) {
+                int w[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) w[p] = 0;
+                const uint32_t *src = s_row + yl * CAP;
+                if (src[0] == 0xffffffffu) {
+                    const float cyr = row_cy(yl);
+                    for (uint32_t p = 0; p < nvalid; ++p)
+                        w[p] = brute_winding(gb, gp, rec_cnt, col_cx((uint32_t)j0 + p), cyr);
+                } else {
+                    int prev = 0;
+                    for (int i = 0; i < CAP; ++i) {
+                        const uint32_t en = src[i];
+                        const int bq = (int)(en >> 16);
+                        const int v = (int)(int16_t)(en & 0xffffu);
+#pragma unroll
+                        for (int p = 0; p < 16; ++p) {
+                            const int j = j0 + p;
+                            if (j >= prev && j < bq) w[p] = v;
+                        }
+                        prev = bq;
+                        if (bq == 0xffff) break;
+                    }
+                }
+                const size_t eidx = (out_row0 + yl) * A.out_stride + out_col0 + px0;
+                if (MODE == MODE_WINDING_I16) {
+                    int16_t *dst = reinterpret_cast<int16_t *>(A.out) + eidx;
+                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                        uint32_t pk[8];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            pk[p] = ((uint32_t)w[2 * p] & 0xffffu) | ((uint32_t)w[2 * p + 1] << 16);
+                        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    } else {
+                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (int16_t)w[p];
+                    }
+                } else {
+                    uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const uint32_t v = (MODE == MODE_GRAY_DEBUG) ? gray_debug(w[p]) : (w[p] != 0 ? 255u : 0u);
+                        pk[p >> 2] |= v << (8 * (p & 3));
+                    }
+                    uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
+                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    } else {
+                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
+                    }
+                }
+            }
+        }
     }
-    (void)esz;
 }
 
-size_t render_lds_bytes(uint32_t strip_w, int n, uint32_t kmax)
+// LDS plan: region A = [cx table | staged records] (phase 0/1), reused by region B =
+// window masks (coverage) or breakpoint rows (winding modes); then s_fill[256], s_nact.
+void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *nwin_log,
+                     uint32_t *tail, size_t *total)
 {
-    return (size_t)strip_w * n * 4 + 256 * sizeof(RecBounds) + 256 * sizeof(RecPayload) +
-           (size_t)kmax * 256 * 4 + 256 * 4 + 16;
+    uint32_t nwin = (strip_w + 15u) / 16u, lg = 0;
+    while ((1u << lg) < nwin) ++lg;
+    const size_t a = (size_t)strip_w * n * 4 + 256 * sizeof(RecLds);
+    const size_t b = mode == MODE_COVERAGE_U8 ? (size_t)256 * (8u << lg) : (size_t)256 * cap * 4;
+    const size_t t = ((a > b ? a : b) + 15) & ~(size_t)15;
+    *nwin_log = lg; *tail = (uint32_t)t; *total = t + 256 * 4 + 16;
 }
 
-template <int MODE, int N>
-static hipError_t launch_one(const RenderArgs &a, dim3 grid, size_t lds, hipStream_t stream)
+template <int MODE, int N, int CAP>
+static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 {
-    auto kern = render_kernel<MODE, N>;
+    size_t lds;
+    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_tail, &lds);
+    auto kern = render_kernel<MODE, N, CAP>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -311,20 +404,28 @@ static hipError_t launch_one(const RenderArgs &a, dim3 grid, size_t lds, hipStre
     return hipGetLastError();
 }
 
+template <int MODE, int N>
+static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
+{
+    if (a.kmax <= 8) return launch_one<MODE, N, 8>(a, grid, stream);
+    if (a.kmax <= 16) return launch_one<MODE, N, 16>(a, grid, stream);
+    return launch_one<MODE, N, 32>(a, grid, stream);
+}
+
 hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t stream)
 {
-    const size_t lds = render_lds_bytes(a.strip_w, n, a.kmax);
     const dim3 grid((uint32_t)((size_t)a.n_jobs * a.bands * a.strips));
+    if (a.strip_w == 0 || a.strip_w > 256u || (a.strip_w & 15u)) return hipErrorInvalidValue;
     if (mode == MODE_COVERAGE_U8) {
-        if (n == 1) return launch_one<MODE_COVERAGE_U8, 1>(a, grid, lds, stream);
-        if (n == 2) return launch_one<MODE_COVERAGE_U8, 2>(a, grid, lds, stream);
-        if (n == 4) return launch_one<MODE_COVERAGE_U8, 4>(a, grid, lds, stream);
+        if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1>(a, grid, stream);
+        if (n == 2) return launch_cap<MODE_COVERAGE_U8, 2>(a, grid, stream);
+        if (n == 4) return launch_cap<MODE_COVERAGE_U8, 4>(a, grid, stream);
         return hipErrorInvalidValue;
     }
     if (n != 1) return hipErrorInvalidValue;
-    if (mode == MODE_WINDING_I16) return launch_one<MODE_WINDING_I16, 1>(a, grid, lds, stream);
-    if (mode == MODE_GRAY_DEBUG) return launch_one<MODE_GRAY_DEBUG, 1>(a, grid, lds, stream);
-    if (mode == MODE_MASK_NONZERO) return launch_one<MODE_MASK_NONZERO, 1>(a, grid, lds, stream);
+    if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1>(a, grid, stream);
+    if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1>(a, grid, stream);
+    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_MASK_NONZERO, 1>(a, grid, stream);
     return hipErrorInvalidValue;
 }
 

@@ -94,8 +94,9 @@ const char *fr_last_error(void);
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out);
 void fr_ctx_destroy(fr_ctx *ctx);
 int fr_ctx_sync(fr_ctx *ctx);
-/* tuning / test knobs: "kmax" (crossings kept per sample row before the exact
- * direct-sum fallback, 1..128, default 32), "max_cols" (sample columns per strip) */
+/* tuning / test knobs: "kmax" (crossings kept per sample row, in registers, before the
+ * exact direct-sum fallback: rounded up to 8, 16 or 32; default 16), "strip_px" (column
+ * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip) */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 
 /* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------

@@ -103,34 +103,37 @@ def test_ragged_cells_unaligned_output(ctx, oracle, ascii_set):
 
 
 def test_overfull_rows_take_the_exact_fallback(ctx, oracle):
-    """a comb with 40 teeth: 80 crossings per ray > kmax -> direct-sum fallback; also kmax = 2"""
-    cs, box = comb_glyph(40)
-    g = Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs])
-    gs = GlyphSet([g])
-    jobs = cell_jobs(gs, 192, 180, 2048, 1)
+    """combs with 40 / 6 teeth: 80 / 12 crossings per ray.  The kernel keeps 8, 16 or 32 crossings
+    per sample row in registers (kmax option); fuller rows take the exact direct-sum fallback."""
+    gl = []
+    for teeth in (40, 6):
+        cs, box = comb_glyph(teeth)
+        gl.append(Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs]))
+    gs = GlyphSet(gl)
+    jobs = cell_jobs(gs, 192, 180, 2048, 2)
     try:
-        for kmax in (32, 2, 1):
+        for kmax in (32, 16, 8):
             ctx.set_option("kmax", kmax)
             for mode, n in [(fr.FR_COVERAGE_U8, 4), (fr.FR_WINDING_I16, 1), (fr.FR_COVERAGE_U8, 2)]:
-                got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (192, 192), n, True)
+                got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (192, 384), n, True)
                 assert np.array_equal(got, ref), (kmax, mode, n)
-        ctx.set_option("kmax", 3)
+        ctx.set_option("kmax", 8)
         sg = synth_glyphset(6, 48, first_index=900)
         sj = cell_jobs(sg, 80, 80, 2048, 3)
         got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_COVERAGE_U8, atlas_shape(6, 80, 3), 4, True)
         assert np.array_equal(got, ref)
     finally:
-        ctx.set_option("kmax", 32)
+        ctx.set_option("kmax", 16)
 
 
 def test_wide_cells_are_split_into_strips(ctx, oracle, ascii_set):
-    """a 700-pixel-wide render needs 2800 sample columns > max_cols: column strips"""
+    """a 700-pixel-wide render: column strips of 256 px (default) and of 48 px"""
     i = ascii_set.find("DejaVu", "W")
     g, upm = ascii_set.glyph(i), int(ascii_set.g_upm[i])
     gs = GlyphSet([g])
     try:
-        for max_cols in (2048, 256):
-            ctx.set_option("max_cols", max_cols)
+        for max_cols in (256, 48):
+            ctx.set_option("strip_px", max_cols)
             jobs = cell_jobs(gs, 700, 600, upm, 1)
             jobs["h"] = 90
             jobs["max_y"] -= 200
@@ -139,7 +142,7 @@ def test_wide_cells_are_split_into_strips(ctx, oracle, ascii_set):
             got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_GRAY_DEBUG, (90, 700))
             assert np.array_equal(got, ref), max_cols
     finally:
-        ctx.set_option("max_cols", 2048)
+        ctx.set_option("strip_px", 256)
 
 
 def test_edge_cases(ctx, oracle):
