@@ -15,8 +15,8 @@
 #include <vector>
 
 namespace fr {
-void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, RecBounds *,
-                    RecPayload *, uint32_t *, hipStream_t);
+void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *, uint32_t *,
+                    hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
                        uint8_t *, hipStream_t);
@@ -51,8 +51,9 @@ struct fr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    uint32_t kmax = 16;          // crossings kept per sample row (register array: 8, 16 or 32) before the direct-sum fallback
+    uint32_t kmax = 32;          // crossings kept per sample row (register array: 8, 16 or 32) before the direct-sum fallback
     uint32_t strip_px = 256;     // column strip width, pixels (multiple of 16, <= 256)
+    uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
 };
 
 struct fr_glyphset {
@@ -61,8 +62,7 @@ struct fr_glyphset {
     uint64_t n_points = 0;
     int16_t *d_pts = nullptr;
     uint32_t *d_seg_p0 = nullptr, *d_seg_prev = nullptr, *d_glyph_seg_start = nullptr, *d_rec_count = nullptr;
-    fr::RecBounds *d_bounds = nullptr;
-    fr::RecPayload *d_payload = nullptr;
+    fr::Rec *d_recs = nullptr;
 };
 
 struct fr_plan {
@@ -137,6 +137,11 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
         ctx->strip_px = (uint32_t)value;
         return FR_OK;
     }
+    if (!strcmp(key, "min_wgs")) {
+        if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
+        ctx->min_wgs = (uint32_t)value;
+        return FR_OK;
+    }
     return fail(FR_E_INVALID, "fr_ctx_set_option: unknown key '%s'", key);
 }
 
@@ -174,7 +179,7 @@ void fr_glyphset_destroy(fr_glyphset *gs)
     (void)hipSetDevice(gs->ctx->device);
     (void)hipStreamSynchronize(gs->ctx->stream);
     dfree(gs->d_pts); dfree(gs->d_seg_p0); dfree(gs->d_seg_prev); dfree(gs->d_glyph_seg_start);
-    dfree(gs->d_rec_count); dfree(gs->d_bounds); dfree(gs->d_payload);
+    dfree(gs->d_rec_count); dfree(gs->d_recs);
     delete gs;
 }
 
@@ -182,8 +187,8 @@ int fr_glyphset_prepare(fr_glyphset *gs)
 {
     if (!gs) return fail(FR_E_INVALID, "fr_glyphset_prepare: NULL");
     HIP_TRY(hipSetDevice(gs->ctx->device));
-    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, gs->n_glyphs, gs->d_bounds,
-                       gs->d_payload, gs->d_rec_count, gs->ctx->stream);
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, gs->n_glyphs, gs->d_recs,
+                       gs->d_rec_count, gs->ctx->stream);
     HIP_TRY(hipGetLastError());
     return FR_OK;
 }
@@ -229,8 +234,7 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     GS_TRY(hipMalloc(&gs->d_seg_prev, nseg1 * 4));
     GS_TRY(hipMalloc(&gs->d_glyph_seg_start, ((size_t)n_glyphs + 1) * 4));
     GS_TRY(hipMalloc(&gs->d_rec_count, ((size_t)n_glyphs + 1) * 4));
-    GS_TRY(hipMalloc(&gs->d_bounds, 2 * nseg1 * sizeof(fr::RecBounds)));
-    GS_TRY(hipMalloc(&gs->d_payload, 2 * nseg1 * sizeof(fr::RecPayload)));
+    GS_TRY(hipMalloc(&gs->d_recs, 2 * nseg1 * sizeof(fr::Rec)));
     hipStream_t st = ctx->stream;
     if (np) GS_TRY(hipMemcpyAsync(gs->d_pts, points_xy, np * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
     if (gs->n_seg) {
@@ -239,8 +243,8 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     }
     GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
     GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
-    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, n_glyphs, gs->d_bounds,
-                       gs->d_payload, gs->d_rec_count, st);
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, n_glyphs, gs->d_recs,
+                       gs->d_rec_count, st);
     GS_TRY(hipGetLastError());
     GS_TRY(hipStreamSynchronize(st));   // host vectors above die with this frame
 #undef GS_TRY
@@ -363,14 +367,19 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.jobs = plan->d_jobs;
     a.glyph_seg_start = plan->gs->d_glyph_seg_start;
     a.glyph_rec_count = plan->gs->d_rec_count;
-    a.bounds = plan->gs->d_bounds;
-    a.payload = plan->gs->d_payload;
+    a.recs = plan->gs->d_recs;
     a.out = out_dev;
     a.out_stride = out_stride;
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
     a.nwin_log = 0; a.lds_tail = 0;
+    // one workgroup walks all bands of its cell (cx table, job and records staged once)
+    // unless the batch is too small to fill the chip: then split the bands over workgroups
+    uint32_t bpw = plan->bands;
+    while (bpw > 1 && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = (bpw + 1) / 2;
+    a.bands_per_wg = bpw;
+    a.band_groups = (plan->bands + bpw - 1) / bpw;
     HIP_TRY(hipSetDevice(plan->ctx->device));
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;

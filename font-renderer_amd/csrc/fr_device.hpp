@@ -21,17 +21,13 @@ namespace fr {
 // reference ACCEPTS this root (delta >= 0 and 0 <= t < 1, :52,:59,:64).  The
 // interval is exact, not an estimate — see fr_prepare.hip.
 // ---------------------------------------------------------------------------
-struct __attribute__((aligned(8))) RecBounds {
-    float lo, hi;
-};
-
-// payload, 32 B = two dwordx4:
-//   quadratic: a, B = p0y - p1y, c1 = p1y*p1y, c2 = p0y*p2y, Ax, Bx, p0x, flags
-//   linear   : 0, p0y,           den = p2y-p0y, 0,            Ax, Bx, p0x, flags
+// 48 B = three dwordx4:
+//   quadratic: lo, hi, a, B = p0y - p1y, c1 = p1y*p1y, c2 = p0y*p2y, Ax, Bx, p0x, flags
+//   linear   : lo, hi, 0, p0y,           den = p2y-p0y, 0,            Ax, Bx, p0x, flags
 //   Ax = (p0x - 2*p1x) + p2x, Bx = 2*(p1x - p0x)               (:53, :65)
-struct __attribute__((aligned(16))) RecPayload {
-    float a, b, c1, c2, ax, bx, p0x;
-    uint32_t flags;
+struct __attribute__((aligned(16))) Rec {
+    float lo, hi, a, b, c1, c2, ax, bx, p0x;
+    uint32_t flags, pad0, pad1;
 };
 enum : uint32_t {
     REC_LINEAR = 1u,     // a == 0 branch
@@ -52,11 +48,11 @@ struct RenderArgs {
     const Job *jobs;
     const uint32_t *glyph_seg_start;   // record slice of glyph g starts at 2*glyph_seg_start[g]
     const uint32_t *glyph_rec_count;
-    const RecBounds *bounds;
-    const RecPayload *payload;
+    const Rec *recs;
     void *out;
     uint64_t out_stride;               // elements
     uint32_t n_jobs, bands, strips, strip_w, kmax;
+    uint32_t bands_per_wg, band_groups;   // a workgroup walks bands_per_wg consecutive bands of its cell
     int32_t phase_center;
     uint32_t nwin_log, lds_tail;       // filled by launch_render (LDS plan)
 };
@@ -79,19 +75,19 @@ __host__ __device__ inline float key2f(uint32_t k)
 // t of a record at ray height cy — the reference's operation order, one rounding
 // per operation:  delta = ((cy*a) + c1) - c2 (:58);  t = (B +/- sqrt(delta)) / a (:60-61)
 //                 linear: t = (cy - p0y) / (p2y - p0y) (:51)
-__device__ __forceinline__ float rec_t_quad(const RecPayload &r, float cy)
+__device__ __forceinline__ float rec_t_quad(const Rec &r, float cy)
 {
     float delta = cy * r.a + r.c1 - r.c2;
     float sq = __builtin_sqrtf(delta);
     float num = (r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq);
     return num / r.a;
 }
-__device__ __forceinline__ float rec_t_lin(const RecPayload &r, float cy)
+__device__ __forceinline__ float rec_t_lin(const Rec &r, float cy)
 {
     return (cy - r.b) / r.c1;
 }
 // x of the crossing and the sign it adds (:53-55, :65-68)
-__device__ __forceinline__ void rec_cross(const RecPayload &r, float cy, float &xx, int &sgn)
+__device__ __forceinline__ void rec_cross(const Rec &r, float cy, float &xx, int &sgn)
 {
     float t;
     if (r.flags & REC_LINEAR) {

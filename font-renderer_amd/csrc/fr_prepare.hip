@@ -21,7 +21,7 @@
 namespace fr {
 
 // 0 = cy lies below the accepted interval, 1 = accepted, 2 = above
-__device__ __forceinline__ int classify(const RecPayload &r, float cy)
+__device__ __forceinline__ int classify(const Rec &r, float cy)
 {
     if (r.flags & REC_LINEAR) {
         float t = rec_t_lin(r, cy);
@@ -39,7 +39,7 @@ __device__ __forceinline__ int classify(const RecPayload &r, float cy)
     return 1;
 }
 
-__device__ inline bool accept_interval(const RecPayload &r, float &lo, float &hi)
+__device__ inline bool accept_interval(const Rec &r, float &lo, float &hi)
 {
     const uint32_t kmin = f2key(-3.402823466e+38f), kmax = f2key(3.402823466e+38f);
     // first key whose class is >= 1
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
                                                      const uint32_t *__restrict__ seg_p0,
                                                      const uint32_t *__restrict__ glyph_seg_start,
                                                      uint32_t n_glyphs,
-                                                     RecBounds *__restrict__ out_bounds,
-                                                     RecPayload *__restrict__ out_payload,
+                                                     Rec *__restrict__ out_recs,
                                                      uint32_t *__restrict__ glyph_rec_count)
 {
     const uint32_t g = blockIdx.x;
@@ -83,7 +82,8 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
     for (uint32_t base = 0; base < n_cand; base += 64u) {
         const uint32_t c = base + lane;
         bool valid = false;
-        RecPayload r;
+        Rec r;
+        r.pad0 = 0; r.pad1 = 0;
         float lo = 0.f, hi = 0.f;
         if (c < n_cand) {
             const uint32_t s = s0 + (c >> 1);
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
         const unsigned long long m = __ballot(valid);
         if (valid) {
             const uint32_t pos = n_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            out_bounds[out_base + pos] = RecBounds{lo, hi};
-            out_payload[out_base + pos] = r;
+            r.lo = lo; r.hi = hi;
+            out_recs[out_base + pos] = r;
         }
         n_out += (uint32_t)__popcll(m);
     }
@@ -122,12 +122,11 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
 }
 
 void launch_prepare(const int16_t *pts, const uint32_t *seg_p0, const uint32_t *glyph_seg_start,
-                    uint32_t n_glyphs, RecBounds *out_bounds, RecPayload *out_payload,
-                    uint32_t *glyph_rec_count, hipStream_t stream)
+                    uint32_t n_glyphs, Rec *out_recs, uint32_t *glyph_rec_count, hipStream_t stream)
 {
     if (n_glyphs == 0) return;
     hipLaunchKernelGGL(prepare_kernel, dim3(n_glyphs), dim3(64), 0, stream, pts, seg_p0,
-                       glyph_seg_start, n_glyphs, out_bounds, out_payload, glyph_rec_count);
+                       glyph_seg_start, n_glyphs, out_recs, glyph_rec_count);
 }
 
 }  // namespace fr

@@ -35,16 +35,14 @@ namespace fr {
 enum { MODE_WINDING_I16 = 0, MODE_GRAY_DEBUG = 1, MODE_MASK_NONZERO = 2, MODE_COVERAGE_U8 = 3 };
 
 // direct sum over the glyph's records — the fallback for over-full rows
-__device__ __noinline__ int brute_winding(const RecBounds *__restrict__ bounds,
-                                          const RecPayload *__restrict__ payload, uint32_t n,
-                                          float cx, float cy)
+__device__ __noinline__ int brute_winding(const Rec *__restrict__ recs, uint32_t n, float cx, float cy)
 {
     int w = 0;
     for (uint32_t c = 0; c < n; ++c) {
-        const RecBounds b = bounds[c];
-        if (cy >= b.lo && cy <= b.hi) {
+        const Rec r = recs[c];
+        if (cy >= r.lo && cy <= r.hi) {
             float xx; int sgn;
-            rec_cross(payload[c], cy, xx, sgn);
+            rec_cross(r, cy, xx, sgn);
             if (!(xx < cx)) w += sgn;
         }
     }
@@ -57,17 +55,34 @@ __device__ __forceinline__ uint32_t gray_debug(int w)
     return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-struct __attribute__((aligned(16))) RecLds {    // 48 B: bounds + payload, one per lane in phase 1
-    float lo, hi, a, b, c1, c2, ax, bx, p0x;
-    uint32_t flags, pad0, pad1;
-};
-
 __device__ __forceinline__ float bcast(float v, uint32_t k)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)k));
 }
 
 constexpr uint32_t EMPTY = 0xffffffffu;
+
+// Diagnostic build only (make STAMPS=1 -> libfr_raster_stamps.so): per-phase shader-clock
+// sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
+// library is built without FR_STAMPS and executes no stamp.
+#ifdef FR_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long t_;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (tid == 0) atomicAdd(&g_stamps[i], t_ - t_prev_);                              \
+        t_prev_ = t_;                                                                     \
+    } while (0)
+#define STAMP_INIT()                                                                      \
+    unsigned long long t_prev_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_)::"memory")
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_INIT() do {} while (0)
+#endif
 
 // LDS line of sample row r in the window-mask array.  Swapping line parity with bit 2
 // puts rows r and r+4 (the same sub-row of two adjacent pixel rows, read together by one
@@ -77,7 +92,7 @@ __device__ __forceinline__ uint32_t mask_line(uint32_t r) { return r ^ ((r >> 2)
 template <int MODE, int N, int CAP>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
-    constexpr uint32_t BAND = 256u / N;         // pixel rows per workgroup
+    constexpr uint32_t BAND = 256u / N;         // pixel rows per band
     constexpr int WCOLS = 16 * N;               // sample columns per 16-pixel window (<= 64)
     constexpr int WSHIFT = (N == 4) ? 6 : (N == 2 ? 5 : 4);
     constexpr unsigned long long WALL = (N == 4) ? ~0ull : ((1ull << WCOLS) - 1ull);
@@ -85,29 +100,42 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     extern __shared__ __align__(16) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    STAMP_INIT();
     uint32_t bid = blockIdx.x;
     const uint32_t strip = bid % A.strips; bid /= A.strips;
-    const uint32_t band = bid % A.bands;
-    const uint32_t jidx = bid / A.bands;
+    const uint32_t bgrp = bid % A.band_groups;
+    const uint32_t jidx = bid / A.band_groups;
     const Job job = A.jobs[jidx];
-    const uint32_t y0 = band * BAND, x0s = strip * A.strip_w;
-    if (y0 >= job.h || x0s >= job.w) return;                    // workgroup-uniform
-    const uint32_t band_rows = min(BAND, job.h - y0);
+    const uint32_t x0s = strip * A.strip_w;
+    const uint32_t band_first = bgrp * A.bands_per_wg;
+    if (band_first * BAND >= job.h || x0s >= job.w) return;     // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + BAND - 1u) / BAND);
     const uint32_t sw = min(A.strip_w, job.w - x0s);            // strip width, pixels
     const uint32_t ncol = sw * N;                               // sample columns in the strip
-    const uint32_t nrows = band_rows * N;                       // sample rows in the band
     const int phase = A.phase_center;
     const uint32_t nwin_log = A.nwin_log;                       // windows per row, padded to 2^k
     const uint32_t nwin_pad = 1u << nwin_log;
 
-    // LDS: [cx table | staged records] are dead once phase 1 ends; the window masks
-    // (coverage) or breakpoint rows (winding modes) of phase 1b/2 reuse the same bytes.
+    // this lane's record of the glyph (record tid of the current 256-record chunk): issued
+    // first so its latency hides under the cx-table divisions; for glyphs of <= 256 records
+    // (the common case) it is loaded ONCE and re-culled per band from registers
+    const uint32_t g = job.glyph;
+    const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[g];
+    const uint32_t rec_cnt = A.glyph_rec_count[g];
+    Rec rg;
+    rg.lo = 1.0f; rg.hi = 0.0f;                 // empty interval
+    if (tid < rec_cnt) rg = grec[tid];
+
+    // LDS: cx table (lives for the whole cell) | region R | s_fill[256] | s_nact[2].
+    // Region R holds the staged records during phase 1 and is reused by the window masks
+    // (coverage) / breakpoint rows (winding modes) of phase 1b/2.
     float *s_cx = reinterpret_cast<float *>(smem);
-    RecLds *s_rec = reinterpret_cast<RecLds *>(s_cx + (size_t)A.strip_w * N);
-    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(smem);   // [256][nwin_pad]
-    uint32_t *s_row = reinterpret_cast<uint32_t *>(smem);                        // [256][CAP]
-    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail);          // [256]
-    uint32_t *s_nact = s_fill + 256;
+    unsigned char *regionR = smem + (size_t)A.strip_w * N * 4;
+    Rec *s_rec = reinterpret_cast<Rec *>(regionR);
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(regionR);   // [256][nwin_pad]
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(regionR);                        // [256][CAP]
+    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail);             // [256]
+    uint32_t *s_nact = s_fill + 256;                                                // [2], zeroed below
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
@@ -115,6 +143,19 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         return ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
     };
     for (uint32_t j = tid; j < ncol; j += 256u) s_cx[j] = col_cx(j);
+    if (tid < 2) s_nact[tid] = 0;
+
+    // guess for J from the affine map, fixed up against the exact table
+    const float jscale = job.scale * (float)N;
+    const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
+    const size_t out_col0 = (size_t)job.out_x + x0s;
+    uint32_t flip = 0;                          // which s_nact counter the next chunk uses
+    STAMP(0);                                   // setup: job, record load, cx table
+
+  for (uint32_t band = band_first; band < band_end; ++band) {
+    const uint32_t y0 = band * BAND;
+    const uint32_t band_rows = min(BAND, job.h - y0);
+    const uint32_t nrows = band_rows * N;                       // sample rows in the band
 
     // ray height of sample row r of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
     auto row_cy = [&](uint32_t r) -> float {
@@ -125,54 +166,39 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const float cy = row_cy(row_valid ? tid : 0u);
     const float cy_top = row_cy(0u), cy_bot = row_cy(nrows - 1u);  // cy is non-increasing in r
 
-    const uint32_t g = job.glyph;
-    const size_t rec_off = 2u * (size_t)A.glyph_seg_start[g];
-    const uint32_t rec_cnt = A.glyph_rec_count[g];
-    const RecBounds *gb = A.bounds + rec_off;
-    const RecPayload *gp = A.payload + rec_off;
-
-    // guess for J from the affine map, fixed up against the exact table
-    const float jscale = job.scale * (float)N;
-    const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
-
     uint32_t e[CAP];                            // sorted ascending: (J << 16) | (sign & 0xffff)
 #pragma unroll
     for (int i = 0; i < CAP; ++i) e[i] = EMPTY;
     bool ovf = false;
 
     for (uint32_t base = 0; base < rec_cnt; base += 256u) {
-        if (tid == 0) *s_nact = 0;
-        __syncthreads();
-        // ---- phase 0: band-level cull + compaction into LDS
-        const uint32_t c = base + tid;
-        bool act = false;
-        RecBounds b;
-        if (c < rec_cnt) {
-            b = gb[c];
-            act = (b.hi >= cy_bot) && (b.lo <= cy_top);
+        if (rec_cnt > 256u && !(base == 0 && band == band_first)) {     // multi-chunk glyph: reload
+            rg.lo = 1.0f; rg.hi = 0.0f;
+            if (base + tid < rec_cnt) rg = grec[base + tid];
         }
+        // region R is free (previous chunk's walk / previous band's phase 2 are done) and the
+        // cx table, s_nact zeroes are visible
+        __syncthreads();
+        // ---- phase 0: band-level cull from registers + compaction into LDS
+        const bool act = (rg.hi >= cy_bot) && (rg.lo <= cy_top) && (rg.lo <= rg.hi);
         const unsigned long long m = __ballot(act);
         uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(s_nact, (uint32_t)__popcll(m));
+        if (lane == 0 && m) wbase = atomicAdd(&s_nact[flip], (uint32_t)__popcll(m));
         wbase = __shfl(wbase, 0);
-        if (act) {
-            const uint32_t idx = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const RecPayload p = gp[c];
-            RecLds r;
-            r.lo = b.lo; r.hi = b.hi; r.a = p.a; r.b = p.b; r.c1 = p.c1; r.c2 = p.c2;
-            r.ax = p.ax; r.bx = p.bx; r.p0x = p.p0x; r.flags = p.flags; r.pad0 = 0; r.pad1 = 0;
-            s_rec[idx] = r;
-        }
+        if (act) s_rec[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rg;
+        if (tid == 0) s_nact[flip ^ 1u] = 0;    // everyone read it before the barrier above
         __syncthreads();
-        const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_nact);
+        STAMP(1);                               // phase 0: cull + compaction
+        const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nact[flip]);
+        flip ^= 1u;
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane
         for (uint32_t cb = 0; cb < nact; cb += 64u) {
-            const RecLds mine = s_rec[min(cb + lane, nact - 1u)];
+            const Rec mine = s_rec[min(cb + lane, nact - 1u)];
             const uint32_t cn = min(64u, nact - cb);
             for (uint32_t k = 0; k < cn; ++k) {
                 const float lo = bcast(mine.lo, k), hi = bcast(mine.hi, k);
                 if (row_valid && cy >= lo && cy <= hi) {
-                    RecPayload r;
+                    Rec r;
                     r.a = bcast(mine.a, k); r.b = bcast(mine.b, k); r.c1 = bcast(mine.c1, k);
                     r.c2 = bcast(mine.c2, k); r.ax = bcast(mine.ax, k); r.bx = bcast(mine.bx, k);
                     r.p0x = bcast(mine.p0x, k);
@@ -187,43 +213,56 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     while (J > 0 && s_cx[J - 1] > xx) --J;
                     if (J > 0) {
                         uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
+                        // sorted insert, registers only: compare-exchange chain, 8 slots at a
+                        // time; stop (wave-uniform) once every lane's carry is the EMPTY sentinel
 #pragma unroll
-                        for (int i = 0; i < CAP; ++i) {     // sorted insert, registers only
-                            const uint32_t mn = min(e[i], x);
-                            x = max(e[i], x);
-                            e[i] = mn;
+                        for (int ch = 0; ch < CAP / 8; ++ch) {
+#pragma unroll
+                            for (int i = ch * 8; i < ch * 8 + 8; ++i) {
+                                const uint32_t mn = min(e[i], x);
+                                x = max(e[i], x);
+                                e[i] = mn;
+                            }
+                            if (__ballot(x != EMPTY) == 0ull) break;
                         }
                         if (x != EMPTY) ovf = true;
                     }
                 }
             }
         }
-        __syncthreads();
+        STAMP(2);                               // phase 1: record walk (this wave)
     }
-    if (rec_cnt == 0) __syncthreads();          // the cx-table writes above vs. the reuse below
+    __syncthreads();                            // every wave is done with the staged records
+    STAMP(3);                                   // phase 1: waiting for the slowest wave
 
     const size_t out_row0 = (size_t)job.out_y + y0;
-    const size_t out_col0 = (size_t)job.out_x + x0s;
 
     if (COV) {
         // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity (register)
         {
+            // zero the mask array cooperatively (consecutive 16-B stores: no bank conflicts)
+            uint4 *z = reinterpret_cast<uint4 *>(regionR);
+            for (uint32_t q = tid; q < (128u << nwin_log); q += 256u) z[q] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
             unsigned long long *line = s_mask + ((size_t)mask_line(tid) << nwin_log);
-            for (uint32_t wv = 0; wv < nwin_pad; ++wv) line[wv] = 0ull;
             uint32_t fill = 0;
             if (!ovf) {
                 int run = 0;
 #pragma unroll
-                for (int i = CAP - 1; i >= 0; --i) {
-                    if (e[i] != EMPTY) {
-                        const int before = run;
-                        run += (int)(int16_t)(e[i] & 0xffffu);
-                        if ((run != 0) != (before != 0)) {
-                            const uint32_t t = e[i] >> 16;                  // 1 .. ncol
-                            const uint32_t wv = (t - 1u) >> WSHIFT;
-                            const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
-                            atomicXor(line + wv, ~0ull >> (64u - cb));
-                            fill ^= (1u << wv) - 1u;                        // every window to the left flips
+                for (int ch = CAP / 8 - 1; ch >= 0; --ch) {
+                    if (__ballot(e[ch * 8] != EMPTY) == 0ull) continue;     // sorted: chunk empty in every lane
+#pragma unroll
+                    for (int i = ch * 8 + 7; i >= ch * 8; --i) {
+                        if (e[i] != EMPTY) {
+                            const int before = run;
+                            run += (int)(int16_t)(e[i] & 0xffffu);
+                            if ((run != 0) != (before != 0)) {
+                                const uint32_t t = e[i] >> 16;                  // 1 .. ncol
+                                const uint32_t wv = (t - 1u) >> WSHIFT;
+                                const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
+                                atomicXor(line + wv, ~0ull >> (64u - cb));
+                                fill ^= (1u << wv) - 1u;                        // every window to the left flips
+                            }
                         }
                     }
                 }
@@ -233,14 +272,16 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     unsigned long long mk = 0;
                     for (int cidx = 0; cidx < WCOLS; ++cidx) {
                         const uint32_t j = (wv << WSHIFT) + (uint32_t)cidx;
-                        if (j < ncol && brute_winding(gb, gp, rec_cnt, col_cx(j), cy) != 0) mk |= 1ull << cidx;
+                        if (j < ncol && brute_winding(grec, rec_cnt, col_cx(j), cy) != 0) mk |= 1ull << cidx;
                     }
                     line[wv] = mk;
                 }
             }
             s_fill[tid] = fill;
         }
+        STAMP(4);                               // phase 1b: zero + toggles
         __syncthreads();
+        STAMP(5);
 
         // ---- phase 2: one lane per 16-pixel window
         const uint32_t wx = tid & (nwin_pad - 1u);
@@ -328,7 +369,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 if (src[0] == 0xffffffffu) {
                     const float cyr = row_cy(yl);
                     for (uint32_t p = 0; p < nvalid; ++p)
-                        w[p] = brute_winding(gb, gp, rec_cnt, col_cx((uint32_t)j0 + p), cyr);
+                        w[p] = brute_winding(grec, rec_cnt, col_cx((uint32_t)j0 + p), cyr);
                 } else {
                     int prev = 0;
                     for (int i = 0; i < CAP; ++i) {
@@ -374,18 +415,33 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             }
         }
     }
+    STAMP(6);                                   // phase 2: windows + stores
+  }   // band loop
 }
 
-// LDS plan: region A = [cx table | staged records] (phase 0/1), reused by region B =
-// window masks (coverage) or breakpoint rows (winding modes); then s_fill[256], s_nact.
+#ifdef FR_STAMPS
+extern "C" int fr_debug_read_stamps(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -2;
+}
+#endif
+
+// LDS plan: cx table | region R = max(staged records, window masks / breakpoint rows) |
+// s_fill[256] | s_nact[2]
 void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *nwin_log,
                      uint32_t *tail, size_t *total)
 {
     uint32_t nwin = (strip_w + 15u) / 16u, lg = 0;
     while ((1u << lg) < nwin) ++lg;
-    const size_t a = (size_t)strip_w * n * 4 + 256 * sizeof(RecLds);
+    const size_t cx = (size_t)strip_w * n * 4;
+    const size_t a = 256 * sizeof(Rec);
     const size_t b = mode == MODE_COVERAGE_U8 ? (size_t)256 * (8u << lg) : (size_t)256 * cap * 4;
-    const size_t t = ((a > b ? a : b) + 15) & ~(size_t)15;
+    const size_t t = (cx + (a > b ? a : b) + 15) & ~(size_t)15;
     *nwin_log = lg; *tail = (uint32_t)t; *total = t + 256 * 4 + 16;
 }
 
@@ -414,7 +470,7 @@ static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
 
 hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t stream)
 {
-    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.bands * a.strips));
+    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
     if (a.strip_w == 0 || a.strip_w > 256u || (a.strip_w & 15u)) return hipErrorInvalidValue;
     if (mode == MODE_COVERAGE_U8) {
         if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1>(a, grid, stream);

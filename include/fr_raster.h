@@ -95,7 +95,7 @@ int fr_ctx_create(int device, void *hip_stream, fr_ctx **out);
 void fr_ctx_destroy(fr_ctx *ctx);
 int fr_ctx_sync(fr_ctx *ctx);
 /* tuning / test knobs: "kmax" (crossings kept per sample row, in registers, before the
- * exact direct-sum fallback: rounded up to 8, 16 or 32; default 16), "strip_px" (column
+ * exact direct-sum fallback: rounded up to 8, 16 or 32; default 32), "strip_px" (column
  * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip) */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 

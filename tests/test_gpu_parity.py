@@ -123,7 +123,7 @@ def test_overfull_rows_take_the_exact_fallback(ctx, oracle):
         got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_COVERAGE_U8, atlas_shape(6, 80, 3), 4, True)
         assert np.array_equal(got, ref)
     finally:
-        ctx.set_option("kmax", 16)
+        ctx.set_option("kmax", 32)
 
 
 def test_wide_cells_are_split_into_strips(ctx, oracle, ascii_set):

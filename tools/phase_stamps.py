@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-clock shares of render_kernel (wave 0 of every workgroup),
+from the STAMPS build (make -C font-renderer_amd/csrc stamps).  Shares only — the stamped
+build's run time is never quoted."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import font_renderer_amd as fr
+from font_renderer_amd import _lib
+_lib.lib_path = lambda: os.path.join(ROOT, "font-renderer_amd", "libfr_raster_stamps.so")
+import torch
+from font_renderer_amd.atlas import atlas_shape, cell_jobs
+from font_renderer_amd.synth import synth_glyphset
+G, cell, S, n, cols = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 256, 128, 4, 64
+lib = fr.load_library()
+gs = synth_glyphset(G, S)
+ctx = fr.Context(0)
+dgs = fr.DeviceGlyphSet(ctx, gs)
+H, W = atlas_shape(G, cell, cols)
+out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+plan = fr.Plan(dgs, cell_jobs(gs, cell, cell, 2048, cols), fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER)
+buf = (C.c_ulonglong * 8)()
+plan.render(out.data_ptr(), W, H); ctx.sync()
+lib.fr_debug_read_stamps(buf, 1)
+plan.render(out.data_ptr(), W, H); ctx.sync()
+lib.fr_debug_read_stamps(buf, 1)
+v = np.array(list(buf), float)[:7]
+names = ["setup(cx,cy)", "phase0 cull+stage", "phase1 walk", "phase1 barrier wait", "phase1b zero+toggles", "barrier", "phase2 windows+stores"]
+for nme, x in zip(names, v):
+    print(f"{nme:24s} {x / v.sum() * 100:6.2f} %   {x / (G * 4):10.0f} cycles/workgroup")
