@@ -10,9 +10,10 @@
 // t+(cy) is non-decreasing / t-(cy) non-increasing for either sign of a.  The
 // three rejection tests are therefore each a one-sided cut of the cy axis, and the
 // accepted set is a closed interval [lo, hi] of binary32 values.  We locate its two
-// ends by bisection over the ordered bit patterns of ALL finite floats, evaluating
-// the reference's own expression (rec_t_quad / rec_t_lin) at each probe — no error
-// analysis, no tolerance.  The same holds for the a == 0 branch (:51-52).
+// ends by searching the ordered bit patterns of ALL finite floats (exponential search out
+// of analytic hints, then bisection), evaluating the reference's own expression
+// (rec_t_quad / rec_t_lin) at each probe — no error analysis, no tolerance: the hints
+// only decide where the search starts, never what it returns.  The same holds for the a == 0 branch (:51-52).
 // With [lo, hi] known the render kernel tests  lo <= cy <= hi  (two compares) instead
 // of solving the quadratic for every (row, segment), and rows outside it are culled
 // with a bit-exact guarantee.
@@ -39,22 +40,53 @@ __device__ __forceinline__ int classify(const Rec &r, float cy)
     return 1;
 }
 
-__device__ inline bool accept_interval(const Rec &r, float &lo, float &hi)
+// Smallest key k in [L, H] such that class(k) >= T, given the invariant
+//   every key <  L has class <  T,   every key >= H has class >= T      (class is monotone).
+// Two-sided exponential search, then bisection: the cut almost always sits a few ulps
+// from one end of the bracket (the ends are the segment's p0y / p2y / vertex height),
+// so this takes ~2*log2(distance) probes instead of 32.
+__device__ inline uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint32_t H)
+{
+    uint32_t step = 1u;
+    while (step < (1u << 30) && H - L > 2u * step) {
+        const uint32_t pl = L + step - 1u;                  // probe near the low end
+        if (classify(r, key2f(pl)) >= T) { H = pl; break; }
+        L = pl + 1u;
+        const uint32_t ph = H - step;                       // probe near the high end (ph >= L here)
+        if (classify(r, key2f(ph)) < T) { L = ph + 1u; break; }
+        H = ph;
+        step <<= 1;
+    }
+    while (L < H) {
+        const uint32_t mid = L + ((H - L) >> 1);
+        if (classify(r, key2f(mid)) >= T) H = mid; else L = mid + 1u;
+    }
+    return L;
+}
+
+__device__ inline bool accept_interval(const Rec &r, float p0y, float p2y, float &lo, float &hi)
 {
     const uint32_t kmin = f2key(-3.402823466e+38f), kmax = f2key(3.402823466e+38f);
-    // first key whose class is >= 1
-    uint32_t a = kmin, b = kmax + 1u;
-    while (a < b) {
-        uint32_t mid = a + ((b - a) >> 1);
-        if (classify(r, key2f(mid)) >= 1) b = mid; else a = mid + 1u;
+    // bracket both cuts with the three heights where they can sit in exact arithmetic:
+    // t = 0 at cy = p0y, t = 1 at cy = p2y, delta = 0 at the parabola's vertex height
+    // y(t) = p0y - 2 B t + a t^2, t_v = B / a
+    float cand[3];
+    int ncand = 2;
+    cand[0] = p0y; cand[1] = p2y;
+    if (!(r.flags & REC_LINEAR)) { cand[2] = p0y - (r.b * r.b) / r.a; ncand = 3; }
+    uint32_t L1 = kmin, H1 = kmax + 1u, L2 = kmin, H2 = kmax + 1u;
+    for (int i = 0; i < ncand; ++i) {
+        float c = cand[i];
+        if (!(c >= -3.402823466e+38f && c <= 3.402823466e+38f)) continue;   // hints only
+        const uint32_t k = f2key(c);
+        const int cl = classify(r, c);
+        if (cl >= 1) { if (k < H1) H1 = k; } else { if (k + 1u > L1) L1 = k + 1u; }
+        if (cl >= 2) { if (k < H2) H2 = k; } else { if (k + 1u > L2) L2 = k + 1u; }
     }
-    const uint32_t first = a;
-    // first key whose class is 2
-    a = kmin; b = kmax + 1u;
-    while (a < b) {
-        uint32_t mid = a + ((b - a) >> 1);
-        if (classify(r, key2f(mid)) >= 2) b = mid; else a = mid + 1u;
-    }
+    const uint32_t first = first_at_least(r, 1, L1, H1);    // first accepted key
+    if (L2 < first) L2 = first;                             // class 2 cannot start below it
+    if (H2 < L2) H2 = L2;
+    const uint32_t a = first_at_least(r, 2, L2, H2);        // first key above the interval
     if (a == kmin || first > a - 1u) return false;
     lo = key2f(first);
     hi = key2f(a - 1u);
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
                 r.flags = root ? REC_NEG_ROOT : 0u;
                 valid = true;
             }
-            if (valid) valid = accept_interval(r, lo, hi);
+            if (valid) valid = accept_interval(r, p0y, p2y, lo, hi);
         }
         const unsigned long long m = __ballot(valid);
         if (valid) {
