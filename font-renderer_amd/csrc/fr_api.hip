@@ -373,7 +373,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
-    a.nwin_log = 0; a.lds_tail = 0;
+    a.nwin_log = 0; a.lds_region = 0; a.lds_tail = 0;
     // one workgroup walks all bands of its cell (cx table, job and records staged once)
     // unless the batch is too small to fill the chip: then split the bands over workgroups
     uint32_t bpw = plan->bands;

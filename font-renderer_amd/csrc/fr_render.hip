@@ -129,21 +129,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     // LDS: cx table (lives for the whole cell) | region R | s_fill[256] | s_nact[2].
     // Region R holds the staged records during phase 1 and is reused by the window masks
     // (coverage) / breakpoint rows (winding modes) of phase 1b/2.
-    float *s_cx = reinterpret_cast<float *>(smem);
-    unsigned char *regionR = smem + (size_t)A.strip_w * N * 4;
+    // s_cxp[0] = -inf, s_cxp[1 + j] = cx(j), s_cxp[1 + ncol] = +inf
+    float *s_cxp = reinterpret_cast<float *>(smem);
+    unsigned char *regionR = smem + A.lds_region;
     Rec *s_rec = reinterpret_cast<Rec *>(regionR);
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(regionR);   // [256][nwin_pad]
     uint32_t *s_row = reinterpret_cast<uint32_t *>(regionR);                        // [256][CAP]
     uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail);             // [256]
     uint32_t *s_nact = s_fill + 256;                                                // [2], zeroed below
+    float *s_cyr = reinterpret_cast<float *>(s_nact + 2);                           // [2] band's top / bottom cy
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     auto col_cx = [&](uint32_t j) -> float {
         return ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
     };
-    for (uint32_t j = tid; j < ncol; j += 256u) s_cx[j] = col_cx(j);
+    for (uint32_t j = tid; j < ncol; j += 256u) s_cxp[1u + j] = col_cx(j);
     if (tid < 2) s_nact[tid] = 0;
+    if (tid == 2) s_cxp[0] = -__builtin_inff();
+    if (tid == 3) s_cxp[1u + ncol] = __builtin_inff();
 
     // guess for J from the affine map, fixed up against the exact table
     const float jscale = job.scale * (float)N;
@@ -164,7 +168,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     };
     const bool row_valid = tid < nrows;
     const float cy = row_cy(row_valid ? tid : 0u);
-    const float cy_top = row_cy(0u), cy_bot = row_cy(nrows - 1u);  // cy is non-increasing in r
+    // cy is non-increasing in r: the band spans [cy(nrows-1), cy(0)], this wave [wcy_bot, wcy_top]
+    if (tid == 0) s_cyr[0] = cy;
+    if (tid == nrows - 1u) s_cyr[1] = cy;
+    const uint32_t wrow0 = tid & ~63u;
+    const bool wave_has_rows = wrow0 < nrows;
+    const float wcy_top = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
+    const float wcy_bot = bcast(cy, wave_has_rows ? min(63u, nrows - 1u - wrow0) : 0u);
 
     uint32_t e[CAP];                            // sorted ascending: (J << 16) | (sign & 0xffff)
 #pragma unroll
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         // cx table, s_nact zeroes are visible
         __syncthreads();
         // ---- phase 0: band-level cull from registers + compaction into LDS
+        const float cy_top = s_cyr[0], cy_bot = s_cyr[1];
         const bool act = (rg.hi >= cy_bot) && (rg.lo <= cy_top) && (rg.lo <= rg.hi);
         const unsigned long long m = __ballot(act);
         uint32_t wbase = 0;
@@ -192,10 +203,14 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nact[flip]);
         flip ^= 1u;
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane
-        for (uint32_t cb = 0; cb < nact; cb += 64u) {
+        for (uint32_t cb = 0; cb < nact && wave_has_rows; cb += 64u) {
             const Rec mine = s_rec[min(cb + lane, nact - 1u)];
-            const uint32_t cn = min(64u, nact - cb);
-            for (uint32_t k = 0; k < cn; ++k) {
+            // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
+            // scalar find-first-set loop — records that miss the wave cost nothing
+            unsigned long long todo = __ballot((cb + lane < nact) && (mine.hi >= wcy_bot) && (mine.lo <= wcy_top));
+            while (todo) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 const float lo = bcast(mine.lo, k), hi = bcast(mine.hi, k);
                 if (row_valid && cy >= lo && cy <= hi) {
                     Rec r;
@@ -206,11 +221,18 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     float xx; int sgn;
                     rec_cross(r, cy, xx, sgn);
                     // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
+                    // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
+                    // map, confirm with one paired read, walk only if the guess is off
                     float gf = xx * jscale - joff;
                     gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
                     int J = (int)gf;
-                    while (J < (int)ncol && s_cx[J] <= xx) ++J;
-                    while (J > 0 && s_cx[J - 1] > xx) --J;
+                    {
+                        const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
+                        if (!(c0 <= xx && xx < c1)) {
+                            while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
+                            while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
+                        }
+                    }
                     if (J > 0) {
                         uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
                         // sorted insert, registers only: compare-exchange chain, 8 slots at a
@@ -431,25 +453,25 @@ extern "C" int fr_debug_read_stamps(unsigned long long *out8, int reset)
 }
 #endif
 
-// LDS plan: cx table | region R = max(staged records, window masks / breakpoint rows) |
-// s_fill[256] | s_nact[2]
+// LDS plan: padded cx table | region R = max(staged records, window masks / breakpoint
+// rows) | s_fill[256] | s_nact[2] | s_cyr[2]
 void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *nwin_log,
-                     uint32_t *tail, size_t *total)
+                     uint32_t *region, uint32_t *tail, size_t *total)
 {
     uint32_t nwin = (strip_w + 15u) / 16u, lg = 0;
     while ((1u << lg) < nwin) ++lg;
-    const size_t cx = (size_t)strip_w * n * 4;
+    const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
     const size_t a = 256 * sizeof(Rec);
     const size_t b = mode == MODE_COVERAGE_U8 ? (size_t)256 * (8u << lg) : (size_t)256 * cap * 4;
     const size_t t = (cx + (a > b ? a : b) + 15) & ~(size_t)15;
-    *nwin_log = lg; *tail = (uint32_t)t; *total = t + 256 * 4 + 16;
+    *nwin_log = lg; *region = (uint32_t)cx; *tail = (uint32_t)t; *total = t + 256 * 4 + 32;
 }
 
 template <int MODE, int N, int CAP>
 static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 {
     size_t lds;
-    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_tail, &lds);
+    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_tail, &lds);
     auto kern = render_kernel<MODE, N, CAP>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
