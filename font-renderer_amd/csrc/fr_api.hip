@@ -69,6 +69,8 @@ struct fr_plan {
     fr_ctx *ctx = nullptr;
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
+    unsigned long long *d_ovf_bits = nullptr;
+    uint32_t *d_ovf_count = nullptr;
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0;
@@ -289,7 +291,7 @@ void fr_plan_destroy(fr_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    dfree(plan->d_jobs);
+    dfree(plan->d_jobs); dfree(plan->d_ovf_bits); dfree(plan->d_ovf_count);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
     delete plan;
@@ -326,7 +328,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (!p) return fail(FR_E_NOMEM, "fr_plan_create: host allocation");
     p->ctx = ctx; p->gs = gs; p->n_jobs = n_jobs; p->params = *params;
     p->pixels = pixels; p->need_cols = need_cols; p->need_rows = need_rows;
-    const uint32_t band = 256u / n;
+    const uint32_t band = 64u / n;                                      // pixel rows per wave band
     const uint32_t cap_w = ctx->strip_px;                               // strip width cap, pixels
     uint32_t sw = (max_w + 15u) & ~15u;
     if (sw > cap_w) sw = cap_w;
@@ -342,6 +344,8 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&p->d_ovf_bits, ((size_t)n_jobs * p->bands * p->strips + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&p->d_ovf_count, 16);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -373,14 +377,18 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
-    a.nwin_log = 0; a.lds_region = 0; a.lds_tail = 0;
+    a.nwin_log = 0; a.lds_region = 0; a.lds_wave_bytes = 0; a.lds_tail = 0;
     // one workgroup walks all bands of its cell (cx table, job and records staged once)
     // unless the batch is too small to fill the chip: then split the bands over workgroups
-    uint32_t bpw = plan->bands;
-    while (bpw > 1 && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = (bpw + 1) / 2;
+    // (bands are wave bands of 64/n pixel rows; a workgroup's 4 waves take them round-robin)
+    uint32_t bpw = (plan->bands + 3u) & ~3u;
+    while (bpw > 4 && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + 3u) & ~3u;
     a.bands_per_wg = bpw;
     a.band_groups = (plan->bands + bpw - 1) / bpw;
+    a.ovf_bits = plan->d_ovf_bits;
+    a.ovf_count = plan->d_ovf_count;
     HIP_TRY(hipSetDevice(plan->ctx->device));
+    HIP_TRY(hipMemsetAsync(plan->d_ovf_count, 0, 4, plan->ctx->stream));
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;
 }

@@ -50,11 +50,13 @@ struct RenderArgs {
     const uint32_t *glyph_rec_count;
     const Rec *recs;
     void *out;
+    unsigned long long *ovf_bits;      // [n_jobs][bands][strips]: over-full sample rows of each wave band
+    uint32_t *ovf_count;               // number of wave bands with any (zeroed before each render)
     uint64_t out_stride;               // elements
     uint32_t n_jobs, bands, strips, strip_w, kmax;
     uint32_t bands_per_wg, band_groups;   // a workgroup walks bands_per_wg consecutive bands of its cell
     int32_t phase_center;
-    uint32_t nwin_log, lds_region, lds_tail;   // filled by launch_render (LDS plan)
+    uint32_t nwin_log, lds_region, lds_wave_bytes, lds_tail;   // filled by launch_render (LDS plan)
 };
 
 // order-preserving map binary32 -> u32 (total order, -0 < +0)

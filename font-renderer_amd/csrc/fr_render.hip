@@ -84,22 +84,33 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP_INIT() do {} while (0)
 #endif
 
-// LDS line of sample row r in the window-mask array.  Swapping line parity with bit 2
-// puts rows r and r+4 (the same sub-row of two adjacent pixel rows, read together by one
-// ds_read_b64 in phase 2) into different 128-B halves of the 256-B bank space.
+// LDS line of sample row r (0..31 of a half band) in a wave's window-mask array.  Swapping
+// line parity with bit 2 puts rows r and r+4 (the same sub-row of two adjacent pixel rows,
+// read together by one ds_read_b64 in phase 2) into different 128-B halves of the bank space.
 __device__ __forceinline__ uint32_t mask_line(uint32_t r) { return r ^ ((r >> 2) & 1u); }
+
+// LDS hand-off inside ONE wave (writer lanes -> reader lanes of the same wave): LDS operations
+// of a wave complete in order, so a drained lgkmcnt plus a compiler barrier is enough — no
+// s_barrier, the other three waves of the workgroup are never waited for.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 template <int MODE, int N, int CAP>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
-    constexpr uint32_t BAND = 256u / N;         // pixel rows per band
+    constexpr uint32_t WBAND = 64u / N;         // pixel rows per wave band (64 sample rows)
+    constexpr uint32_t HROWS = 32u / N;         // pixel rows per half band (32 sample rows)
     constexpr int WCOLS = 16 * N;               // sample columns per 16-pixel window (<= 64)
     constexpr int WSHIFT = (N == 4) ? 6 : (N == 2 ? 5 : 4);
     constexpr unsigned long long WALL = (N == 4) ? ~0ull : ((1ull << WCOLS) - 1ull);
     constexpr bool COV = (MODE == MODE_COVERAGE_U8);
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     STAMP_INIT();
     uint32_t bid = blockIdx.x;
     const uint32_t strip = bid % A.strips; bid /= A.strips;
@@ -107,37 +118,32 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const uint32_t jidx = bid / A.band_groups;
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * A.strip_w;
-    const uint32_t band_first = bgrp * A.bands_per_wg;
-    if (band_first * BAND >= job.h || x0s >= job.w) return;     // workgroup-uniform
-    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + BAND - 1u) / BAND);
+    const uint32_t band_first = bgrp * A.bands_per_wg;          // in wave bands
+    if (band_first * WBAND >= job.h || x0s >= job.w) return;    // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + WBAND - 1u) / WBAND);
     const uint32_t sw = min(A.strip_w, job.w - x0s);            // strip width, pixels
     const uint32_t ncol = sw * N;                               // sample columns in the strip
     const int phase = A.phase_center;
     const uint32_t nwin_log = A.nwin_log;                       // windows per row, padded to 2^k
     const uint32_t nwin_pad = 1u << nwin_log;
 
-    // this lane's record of the glyph (record tid of the current 256-record chunk): issued
-    // first so its latency hides under the cx-table divisions; for glyphs of <= 256 records
-    // (the common case) it is loaded ONCE and re-culled per band from registers
     const uint32_t g = job.glyph;
     const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[g];
     const uint32_t rec_cnt = A.glyph_rec_count[g];
-    Rec rg;
-    rg.lo = 1.0f; rg.hi = 0.0f;                 // empty interval
-    if (tid < rec_cnt) rg = grec[tid];
 
-    // LDS: cx table (lives for the whole cell) | region R | s_fill[256] | s_nact[2].
-    // Region R holds the staged records during phase 1 and is reused by the window masks
-    // (coverage) / breakpoint rows (winding modes) of phase 1b/2.
+    // LDS: padded cx table | staged records (<= 256, read-only while waves walk them) |
+    //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
     // s_cxp[0] = -inf, s_cxp[1 + j] = cx(j), s_cxp[1 + ncol] = +inf
     float *s_cxp = reinterpret_cast<float *>(smem);
-    unsigned char *regionR = smem + A.lds_region;
-    Rec *s_rec = reinterpret_cast<Rec *>(regionR);
-    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(regionR);   // [256][nwin_pad]
-    uint32_t *s_row = reinterpret_cast<uint32_t *>(regionR);                        // [256][CAP]
-    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail);             // [256]
-    uint32_t *s_nact = s_fill + 256;                                                // [2], zeroed below
-    float *s_cyr = reinterpret_cast<float *>(s_nact + 2);                           // [2] band's top / bottom cy
+    Rec *s_rec = reinterpret_cast<Rec *>(smem + A.lds_region);
+    unsigned char *wregion = smem + A.lds_region + 256 * sizeof(Rec) + (size_t)wave * A.lds_wave_bytes;
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(wregion);    // [32][nwin_pad]
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
+    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * 32u; // [32]
+
+    // stage the first (usually only) 256-record chunk: one record per lane, issued first so the
+    // latency hides under the cx-table divisions
+    if (tid < rec_cnt) s_rec[tid] = grec[tid];
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
@@ -145,7 +151,6 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         return ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
     };
     for (uint32_t j = tid; j < ncol; j += 256u) s_cxp[1u + j] = col_cx(j);
-    if (tid < 2) s_nact[tid] = 0;
     if (tid == 2) s_cxp[0] = -__builtin_inff();
     if (tid == 3) s_cxp[1u + ncol] = __builtin_inff();
 
@@ -153,28 +158,24 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const float jscale = job.scale * (float)N;
     const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
     const size_t out_col0 = (size_t)job.out_x + x0s;
-    uint32_t flip = 0;                          // which s_nact counter the next chunk uses
-    STAMP(0);                                   // setup: job, record load, cx table
+    __syncthreads();                            // the ONLY workgroup barrier for glyphs of <= 256 records
+    STAMP(0);                                   // setup: job, record staging, cx table
 
-  for (uint32_t band = band_first; band < band_end; ++band) {
-    const uint32_t y0 = band * BAND;
-    const uint32_t band_rows = min(BAND, job.h - y0);
-    const uint32_t nrows = band_rows * N;                       // sample rows in the band
+  // wave w takes wave bands band_first + w, + 4, ...; every wave runs the same trip count so the
+  // (rare) multi-chunk restaging barriers line up
+  for (uint32_t band0 = band_first; band0 < band_end; band0 += 4u) {
+    const uint32_t band = band0 + wave;
+    const bool band_valid = band < band_end;
+    const uint32_t y0 = band * WBAND;
+    const uint32_t nrows = band_valid ? min(WBAND, job.h - y0) * N : 0u;    // sample rows of my band
 
-    // ray height of sample row r of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
-    auto row_cy = [&](uint32_t r) -> float {
-        const int32_t y = (int32_t)(y0 + r / N);
-        return ((float)(job.max_y - y) - sub_off((int)(r % N), N, phase)) / job.scale;
-    };
-    const bool row_valid = tid < nrows;
-    const float cy = row_cy(row_valid ? tid : 0u);
-    // cy is non-increasing in r: the band spans [cy(nrows-1), cy(0)], this wave [wcy_bot, wcy_top]
-    if (tid == 0) s_cyr[0] = cy;
-    if (tid == nrows - 1u) s_cyr[1] = cy;
-    const uint32_t wrow0 = tid & ~63u;
-    const bool wave_has_rows = wrow0 < nrows;
+    // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
+    const bool row_valid = lane < nrows;
+    const uint32_t rr0 = row_valid ? lane : 0u;
+    const float cy = ((float)(job.max_y - (int32_t)(y0 + rr0 / N)) - sub_off((int)(rr0 % N), N, phase)) / job.scale;
+    // cy is non-increasing in the row index: this wave spans [wcy_bot, wcy_top]
     const float wcy_top = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
-    const float wcy_bot = bcast(cy, wave_has_rows ? min(63u, nrows - 1u - wrow0) : 0u);
+    const float wcy_bot = bcast(cy, nrows ? nrows - 1u : 0u);
 
     uint32_t e[CAP];                            // sorted ascending: (J << 16) | (sign & 0xffff)
 #pragma unroll
@@ -182,32 +183,18 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     bool ovf = false;
 
     for (uint32_t base = 0; base < rec_cnt; base += 256u) {
-        if (rec_cnt > 256u && !(base == 0 && band == band_first)) {     // multi-chunk glyph: reload
-            rg.lo = 1.0f; rg.hi = 0.0f;
-            if (base + tid < rec_cnt) rg = grec[base + tid];
+        if (rec_cnt > 256u) {                   // multi-chunk glyph: restage (workgroup-uniform path)
+            __syncthreads();
+            if (base + tid < rec_cnt) s_rec[tid] = grec[base + tid];
+            __syncthreads();
         }
-        // region R is free (previous chunk's walk / previous band's phase 2 are done) and the
-        // cx table, s_nact zeroes are visible
-        __syncthreads();
-        // ---- phase 0: band-level cull from registers + compaction into LDS
-        const float cy_top = s_cyr[0], cy_bot = s_cyr[1];
-        const bool act = (rg.hi >= cy_bot) && (rg.lo <= cy_top) && (rg.lo <= rg.hi);
-        const unsigned long long m = __ballot(act);
-        uint32_t wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&s_nact[flip], (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (act) s_rec[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rg;
-        if (tid == 0) s_nact[flip ^ 1u] = 0;    // everyone read it before the barrier above
-        __syncthreads();
-        STAMP(1);                               // phase 0: cull + compaction
-        const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nact[flip]);
-        flip ^= 1u;
+        const uint32_t nchunk = min(256u, rec_cnt - base);
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane
-        for (uint32_t cb = 0; cb < nact && wave_has_rows; cb += 64u) {
-            const Rec mine = s_rec[min(cb + lane, nact - 1u)];
+        for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
+            const Rec mine = s_rec[min(cb + lane, nchunk - 1u)];
             // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
             // scalar find-first-set loop — records that miss the wave cost nothing
-            unsigned long long todo = __ballot((cb + lane < nact) && (mine.hi >= wcy_bot) && (mine.lo <= wcy_top));
+            unsigned long long todo = __ballot((cb + lane < nchunk) && (mine.hi >= wcy_bot) && (mine.lo <= wcy_top));
             while (todo) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -252,182 +239,115 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 }
             }
         }
-        STAMP(2);                               // phase 1: record walk (this wave)
     }
-    __syncthreads();                            // every wave is done with the staged records
-    STAMP(3);                                   // phase 1: waiting for the slowest wave
+    STAMP(1);                                   // phase 1: record walk
+    if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
+    // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
+    // publish which of my 64 sample rows they are (one word per wave band, always written)
+    {
+        const unsigned long long ovf_rows = __ballot(ovf);
+        if (lane == 0) A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
+        if (ovf_rows && lane == 0) atomicAdd(A.ovf_count, 1u);
+    }
 
-    const size_t out_row0 = (size_t)job.out_y + y0;
-
-    if (COV) {
-        // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity (register)
-        {
-            // zero the mask array cooperatively (consecutive 16-B stores: no bank conflicts)
-            uint4 *z = reinterpret_cast<uint4 *>(regionR);
-            for (uint32_t q = tid; q < (128u << nwin_log); q += 256u) z[q] = make_uint4(0, 0, 0, 0);
-            __syncthreads();
-            unsigned long long *line = s_mask + ((size_t)mask_line(tid) << nwin_log);
-            uint32_t fill = 0;
-            if (!ovf) {
-                int run = 0;
+    // ---- phases 1b + 2, one half band (32 sample rows) at a time, wave-private LDS
 #pragma unroll
-                for (int ch = CAP / 8 - 1; ch >= 0; --ch) {
-                    if (__ballot(e[ch * 8] != EMPTY) == 0ull) continue;     // sorted: chunk empty in every lane
+    for (uint32_t half = 0; half < 2u; ++half) {
+        if (half * 32u >= nrows) break;                             // wave-uniform
+        const bool mine_half = (lane >> 5) == half;
+        const uint32_t hrow = lane & 31u;                           // my row inside the half
+        const uint32_t prow0 = y0 + half * HROWS;                   // first pixel row of the half
+        const uint32_t prows = min(HROWS, job.h - prow0);           // pixel rows in the half
+        const size_t out_row0 = (size_t)job.out_y + prow0;
+        if (COV) {
+            // zero the half's masks cooperatively (consecutive 16-B stores: no bank conflicts)
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(wregion);
+                for (uint32_t q = lane; q < (16u << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
+            }
+            wave_lds_sync();
+            // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity
+            if (mine_half) {
+                unsigned long long *line = s_mask + ((size_t)mask_line(hrow) << nwin_log);
+                uint32_t fill = 0;
+                if (!ovf) {
+                    int run = 0;
 #pragma unroll
-                    for (int i = ch * 8 + 7; i >= ch * 8; --i) {
-                        if (e[i] != EMPTY) {
-                            const int before = run;
-                            run += (int)(int16_t)(e[i] & 0xffffu);
-                            if ((run != 0) != (before != 0)) {
-                                const uint32_t t = e[i] >> 16;                  // 1 .. ncol
-                                const uint32_t wv = (t - 1u) >> WSHIFT;
-                                const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
-                                atomicXor(line + wv, ~0ull >> (64u - cb));
-                                fill ^= (1u << wv) - 1u;                        // every window to the left flips
+                    for (int ch = CAP / 8 - 1; ch >= 0; --ch) {
+                        if (__ballot(e[ch * 8] != EMPTY) == 0ull) continue;     // sorted: chunk empty in every lane
+#pragma unroll
+                        for (int i = ch * 8 + 7; i >= ch * 8; --i) {
+                            if (e[i] != EMPTY) {
+                                const int before = run;
+                                run += (int)(int16_t)(e[i] & 0xffffu);
+                                if ((run != 0) != (before != 0)) {
+                                    const uint32_t t = e[i] >> 16;                  // 1 .. ncol
+                                    const uint32_t wv = (t - 1u) >> WSHIFT;
+                                    const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
+                                    atomicXor(line + wv, ~0ull >> (64u - cb));
+                                    fill ^= (1u << wv) - 1u;                        // every window to the left flips
+                                }
                             }
                         }
                     }
                 }
-            } else if (row_valid) {
-                // over-full row: direct sum per sample column (same integers, slow path)
-                for (uint32_t wv = 0; wv < nwin_pad; ++wv) {
-                    unsigned long long mk = 0;
-                    for (int cidx = 0; cidx < WCOLS; ++cidx) {
-                        const uint32_t j = (wv << WSHIFT) + (uint32_t)cidx;
-                        if (j < ncol && brute_winding(grec, rec_cnt, col_cx(j), cy) != 0) mk |= 1ull << cidx;
-                    }
-                    line[wv] = mk;
-                }
+                s_fill[hrow] = fill;
             }
-            s_fill[tid] = fill;
-        }
-        STAMP(4);                               // phase 1b: zero + toggles
-        __syncthreads();
-        STAMP(5);
+            wave_lds_sync();
+            STAMP(2);                           // phase 1b: zero + toggles
 
-        // ---- phase 2: one lane per 16-pixel window
-        const uint32_t wx = tid & (nwin_pad - 1u);
-        const uint32_t px0 = wx * 16u;
-        if (px0 < sw) {
-            const uint32_t nvalid = min(16u, sw - px0);
-            for (uint32_t yl = tid >> nwin_log; yl < band_rows; yl += (256u >> nwin_log)) {
-                unsigned long long mask[N];
+            // ---- phase 2: one lane per 16-pixel window
+            const uint32_t wx = lane & (nwin_pad - 1u);
+            const uint32_t px0 = wx * 16u;
+            if (px0 < sw) {
+                const uint32_t nvalid = min(16u, sw - px0);
+                for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) {
+                    unsigned long long mask[N];
 #pragma unroll
-                for (int rr = 0; rr < N; ++rr) {
-                    const uint32_t r = yl * N + rr;
-                    const unsigned long long mk = s_mask[((size_t)mask_line(r) << nwin_log) + wx];
-                    mask[rr] = mk ^ (((s_fill[r] >> wx) & 1u) ? WALL : 0ull);
-                }
-                uint32_t pk[4];
-                if (N == 4) {
-                    // SWAR: per-nibble popcounts of the 4 sample rows, summed per pixel
-                    unsigned long long s01 = 0, s23 = 0;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        unsigned long long x = mask[rr];
-                        x = x - ((x >> 1) & 0x5555555555555555ull);
-                        x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
-                        if (rr < 2) s01 += x; else s23 += x;
+                    for (int rr = 0; rr < N; ++rr) {
+                        const uint32_t r = yl * N + rr;
+                        const unsigned long long mk = s_mask[((size_t)mask_line(r) << nwin_log) + wx];
+                        mask[rr] = mk ^ (((s_fill[r] >> wx) & 1u) ? WALL : 0ull);
                     }
-                    const unsigned long long M = 0x0f0f0f0f0f0f0f0full;
-                    const unsigned long long ke = (s01 & M) + (s23 & M);                 // even pixels, 0..16
-                    const unsigned long long ko = ((s01 >> 4) & M) + ((s23 >> 4) & M);   // odd pixels
-                    // round_half_up(255*k/16) = 16k - (k > 8), per byte, in independent 32-bit halves
-                    uint32_t ve[2], vo[2];
+                    uint32_t pk[4];
+                    if (N == 4) {
+                        // SWAR: per-nibble popcounts of the 4 sample rows, summed per pixel
+                        unsigned long long s01 = 0, s23 = 0;
 #pragma unroll
-                    for (int hlf = 0; hlf < 2; ++hlf) {
-                        const uint32_t a = (uint32_t)(ke >> (32 * hlf)), b2 = (uint32_t)(ko >> (32 * hlf));
-                        ve[hlf] = (a << 4) - (((a + 0x07070707u) >> 4) & 0x01010101u);
-                        vo[hlf] = (b2 << 4) - (((b2 + 0x07070707u) >> 4) & 0x01010101u);
-                    }
-                    pk[0] = __builtin_amdgcn_perm(vo[0], ve[0], 0x05010400u);
-                    pk[1] = __builtin_amdgcn_perm(vo[0], ve[0], 0x07030602u);
-                    pk[2] = __builtin_amdgcn_perm(vo[1], ve[1], 0x05010400u);
-                    pk[3] = __builtin_amdgcn_perm(vo[1], ve[1], 0x07030602u);
-                } else {
-                    pk[0] = pk[1] = pk[2] = pk[3] = 0;
+                        for (int rr = 0; rr < 4; ++rr) {
+                            unsigned long long x = mask[rr];
+                            x = x - ((x >> 1) & 0x5555555555555555ull);
+                            x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
+                            if (rr < 2) s01 += x; else s23 += x;
+                        }
+                        const unsigned long long M = 0x0f0f0f0f0f0f0f0full;
+                        const unsigned long long ke = (s01 & M) + (s23 & M);                 // even pixels, 0..16
+                        const unsigned long long ko = ((s01 >> 4) & M) + ((s23 >> 4) & M);   // odd pixels
+                        // round_half_up(255*k/16) = 16k - (k > 8), per byte, in independent 32-bit halves
+                        uint32_t ve[2], vo[2];
 #pragma unroll
-                    for (int p = 0; p < 16; ++p) {
-                        uint32_t k = 0;
-#pragma unroll
-                        for (int rr = 0; rr < N; ++rr)
-                            k += (uint32_t)__popc((uint32_t)(mask[rr] >> (p * N)) & ((1u << N) - 1u));
-                        const uint32_t v = (2u * 255u * k + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
-                        pk[p >> 2] |= v << (8 * (p & 3));
-                    }
-                }
-                uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + (out_row0 + yl) * A.out_stride + out_col0 + px0;
-                if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                } else {
-                    for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
-                }
-            }
-        }
-    } else {
-        // ---- winding-value modes (N == 1): breakpoints (b_i, winding on [b_{i-1}, b_i)) per row
-        {
-            uint32_t *dst = s_row + tid * CAP;
-            int run = 0;
-#pragma unroll
-            for (int i = CAP - 1; i >= 0; --i) {
-                const bool have = e[i] != EMPTY;
-                if (have) run += (int)(int16_t)(e[i] & 0xffffu);
-                dst[i] = have ? ((e[i] & 0xffff0000u) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
-            }
-            if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
-        }
-        __syncthreads();
-        const uint32_t wx = tid & (nwin_pad - 1u);
-        const uint32_t px0 = wx * 16u;
-        if (px0 < sw) {
-            const uint32_t nvalid = min(16u, sw - px0);
-            const int j0 = (int)px0;
-            for (uint32_t yl = tid >> nwin_log; yl < band_rows; yl += (256u >> nwin_log)) {
-                int w[16];
-#pragma unroll
-                for (int p = 0; p < 16; ++p) w[p] = 0;
-                const uint32_t *src = s_row + yl * CAP;
-                if (src[0] == 0xffffffffu) {
-                    const float cyr = row_cy(yl);
-                    for (uint32_t p = 0; p < nvalid; ++p)
-                        w[p] = brute_winding(grec, rec_cnt, col_cx((uint32_t)j0 + p), cyr);
-                } else {
-                    int prev = 0;
-                    for (int i = 0; i < CAP; ++i) {
-                        const uint32_t en = src[i];
-                        const int bq = (int)(en >> 16);
-                        const int v = (int)(int16_t)(en & 0xffffu);
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const uint32_t a = (uint32_t)(ke >> (32 * hlf)), b2 = (uint32_t)(ko >> (32 * hlf));
+                            ve[hlf] = (a << 4) - (((a + 0x07070707u) >> 4) & 0x01010101u);
+                            vo[hlf] = (b2 << 4) - (((b2 + 0x07070707u) >> 4) & 0x01010101u);
+                        }
+                        pk[0] = __builtin_amdgcn_perm(vo[0], ve[0], 0x05010400u);
+                        pk[1] = __builtin_amdgcn_perm(vo[0], ve[0], 0x07030602u);
+                        pk[2] = __builtin_amdgcn_perm(vo[1], ve[1], 0x05010400u);
+                        pk[3] = __builtin_amdgcn_perm(vo[1], ve[1], 0x07030602u);
+                    } else {
+                        pk[0] = pk[1] = pk[2] = pk[3] = 0;
 #pragma unroll
                         for (int p = 0; p < 16; ++p) {
-                            const int j = j0 + p;
-                            if (j >= prev && j < bq) w[p] = v;
+                            uint32_t k = 0;
+#pragma unroll
+                            for (int rr = 0; rr < N; ++rr)
+                                k += (uint32_t)__popc((uint32_t)(mask[rr] >> (p * N)) & ((1u << N) - 1u));
+                            const uint32_t v = (2u * 255u * k + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
+                            pk[p >> 2] |= v << (8 * (p & 3));
                         }
-                        prev = bq;
-                        if (bq == 0xffff) break;
                     }
-                }
-                const size_t eidx = (out_row0 + yl) * A.out_stride + out_col0 + px0;
-                if (MODE == MODE_WINDING_I16) {
-                    int16_t *dst = reinterpret_cast<int16_t *>(A.out) + eidx;
-                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
-                        uint32_t pk[8];
-#pragma unroll
-                        for (int p = 0; p < 8; ++p)
-                            pk[p] = ((uint32_t)w[2 * p] & 0xffffu) | ((uint32_t)w[2 * p + 1] << 16);
-                        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                    } else {
-                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (int16_t)w[p];
-                    }
-                } else {
-                    uint32_t pk[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int p = 0; p < 16; ++p) {
-                        const uint32_t v = (MODE == MODE_GRAY_DEBUG) ? gray_debug(w[p]) : (w[p] != 0 ? 255u : 0u);
-                        pk[p >> 2] |= v << (8 * (p & 3));
-                    }
-                    uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
+                    uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + (out_row0 + yl) * A.out_stride + out_col0 + px0;
                     if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
                         *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                     } else {
@@ -435,9 +355,81 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     }
                 }
             }
+            wave_lds_sync();                    // masks are re-zeroed by the next half / band
+            STAMP(3);                           // phase 2: windows + stores
+        } else {
+            // ---- winding-value modes (N == 1): breakpoints (b_i, winding on [b_{i-1}, b_i)) per row
+            if (mine_half) {
+                uint32_t *dst = s_row + hrow * CAP;
+                int run = 0;
+#pragma unroll
+                for (int i = CAP - 1; i >= 0; --i) {
+                    const bool have = e[i] != EMPTY;
+                    if (have) run += (int)(int16_t)(e[i] & 0xffffu);
+                    dst[i] = have ? ((e[i] & 0xffff0000u) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
+                }
+                if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
+            }
+            wave_lds_sync();
+            const uint32_t wx = lane & (nwin_pad - 1u);
+            const uint32_t px0 = wx * 16u;
+            if (px0 < sw) {
+                const uint32_t nvalid = min(16u, sw - px0);
+                const int j0 = (int)px0;
+                for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) {
+                    int w[16];
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) w[p] = 0;
+                    const uint32_t *src = s_row + yl * CAP;
+                    if (src[0] == 0xffffffffu) {
+                        // over-full row: fixup_kernel rewrites it
+                    } else {
+                        int prev = 0;
+                        for (int i = 0; i < CAP; ++i) {
+                            const uint32_t en = src[i];
+                            const int bq = (int)(en >> 16);
+                            const int v = (int)(int16_t)(en & 0xffffu);
+#pragma unroll
+                            for (int p = 0; p < 16; ++p) {
+                                const int j = j0 + p;
+                                if (j >= prev && j < bq) w[p] = v;
+                            }
+                            prev = bq;
+                            if (bq == 0xffff) break;
+                        }
+                    }
+                    const size_t eidx = (out_row0 + yl) * A.out_stride + out_col0 + px0;
+                    if (MODE == MODE_WINDING_I16) {
+                        int16_t *dst = reinterpret_cast<int16_t *>(A.out) + eidx;
+                        if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                            uint32_t pk[8];
+#pragma unroll
+                            for (int p = 0; p < 8; ++p)
+                                pk[p] = ((uint32_t)w[2 * p] & 0xffffu) | ((uint32_t)w[2 * p + 1] << 16);
+                            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                        } else {
+                            for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (int16_t)w[p];
+                        }
+                    } else {
+                        uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int p = 0; p < 16; ++p) {
+                            const uint32_t v = (MODE == MODE_GRAY_DEBUG) ? gray_debug(w[p]) : (w[p] != 0 ? 255u : 0u);
+                            pk[p >> 2] |= v << (8 * (p & 3));
+                        }
+                        uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
+                        if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                            *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        } else {
+                            for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
+                        }
+                    }
+                }
+            }
+            wave_lds_sync();
         }
-    }
-    STAMP(6);                                   // phase 2: windows + stores
+    }   // half band
   }   // band loop
 }
 
@@ -453,25 +445,72 @@ extern "C" int fr_debug_read_stamps(unsigned long long *out8, int reset)
 }
 #endif
 
-// LDS plan: padded cx table | region R = max(staged records, window masks / breakpoint
-// rows) | s_fill[256] | s_nact[2] | s_cyr[2]
+// Over-full rows (more than CAP crossings on one sample row — combs, pathological outlines):
+// redo every pixel row that contains one by the direct sum over the glyph's records, the
+// reference's own loop shape (render_glyph.zig:37-71) restricted to accepted roots.  Launched
+// after render_kernel on the same stream; reads the per-wave-band words it published.  Slow,
+// exact, and almost always a no-op (one 8-byte load per wave band).
+template <int MODE, int N>
+__global__ __launch_bounds__(256) void fixup_kernel(const RenderArgs A)
+{
+    constexpr uint32_t WBAND = 64u / N;
+    if (*A.ovf_count == 0u) return;
+    const size_t nwords = (size_t)A.n_jobs * A.bands * A.strips;
+    for (size_t wd = blockIdx.x; wd < nwords; wd += gridDim.x) {
+        const uint32_t strip = (uint32_t)(wd % A.strips);
+        const uint32_t band = (uint32_t)((wd / A.strips) % A.bands);
+        const uint32_t jidx = (uint32_t)(wd / ((size_t)A.strips * A.bands));
+        const Job job = A.jobs[jidx];
+        const uint32_t y0 = band * WBAND, x0s = strip * A.strip_w;
+        if (y0 >= job.h || x0s >= job.w) continue;
+        const unsigned long long bits = A.ovf_bits[wd];
+        if (!bits) continue;
+        const uint32_t sw = min(A.strip_w, job.w - x0s);
+        const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[job.glyph];
+        const uint32_t rec_cnt = A.glyph_rec_count[job.glyph];
+        for (uint32_t pr = 0; pr < WBAND && y0 + pr < job.h; ++pr) {
+            if (!((bits >> (pr * N)) & ((1ull << N) - 1ull))) continue;     // no over-full sample row here
+            const uint32_t y = y0 + pr;
+            for (uint32_t x = threadIdx.x; x < sw; x += 256u) {
+                int inside = 0, w00 = 0;
+                for (int jj = 0; jj < N; ++jj) {
+                    const float cy = ((float)(job.max_y - (int32_t)y) - sub_off(jj, N, A.phase_center)) / job.scale;
+                    for (int ii = 0; ii < N; ++ii) {
+                        const float cx = ((float)(job.min_x + (int32_t)(x0s + x)) + sub_off(ii, N, A.phase_center)) / job.scale;
+                        const int wv = brute_winding(grec, rec_cnt, cx, cy);
+                        if (ii == 0 && jj == 0) w00 = wv;
+                        inside += (wv != 0);
+                    }
+                }
+                const size_t eidx = ((size_t)job.out_y + y) * A.out_stride + job.out_x + x0s + x;
+                if (MODE == MODE_WINDING_I16) reinterpret_cast<int16_t *>(A.out)[eidx] = (int16_t)w00;
+                else if (MODE == MODE_GRAY_DEBUG) reinterpret_cast<uint8_t *>(A.out)[eidx] = (uint8_t)gray_debug(w00);
+                else if (MODE == MODE_MASK_NONZERO) reinterpret_cast<uint8_t *>(A.out)[eidx] = w00 != 0 ? 255 : 0;
+                else reinterpret_cast<uint8_t *>(A.out)[eidx] = (uint8_t)((2 * 255 * inside + N * N) / (2 * N * N));
+            }
+        }
+    }
+}
+
+// LDS plan: padded cx table | staged records [256] | 4 x per-wave half-band region (window
+// masks [32][nwin_pad] u64, or breakpoint rows [32][CAP] u32) | 4 x fill[32]
 void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *nwin_log,
-                     uint32_t *region, uint32_t *tail, size_t *total)
+                     uint32_t *region, uint32_t *wave_bytes, uint32_t *tail, size_t *total)
 {
     uint32_t nwin = (strip_w + 15u) / 16u, lg = 0;
     while ((1u << lg) < nwin) ++lg;
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
-    const size_t a = 256 * sizeof(Rec);
-    const size_t b = mode == MODE_COVERAGE_U8 ? (size_t)256 * (8u << lg) : (size_t)256 * cap * 4;
-    const size_t t = (cx + (a > b ? a : b) + 15) & ~(size_t)15;
-    *nwin_log = lg; *region = (uint32_t)cx; *tail = (uint32_t)t; *total = t + 256 * 4 + 32;
+    const size_t wb = mode == MODE_COVERAGE_U8 ? (size_t)32 * (8u << lg) : (size_t)32 * cap * 4;
+    const size_t t = cx + 256 * sizeof(Rec) + 4 * wb;
+    *nwin_log = lg; *region = (uint32_t)cx; *wave_bytes = (uint32_t)wb; *tail = (uint32_t)t;
+    *total = t + 4 * 32 * 4;
 }
 
 template <int MODE, int N, int CAP>
 static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 {
     size_t lds;
-    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_tail, &lds);
+    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_wave_bytes, &a.lds_tail, &lds);
     auto kern = render_kernel<MODE, N, CAP>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -479,6 +518,11 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t nwords = (size_t)a.n_jobs * a.bands * a.strips;
+    const uint32_t fgrid = (uint32_t)(nwords < 4096 ? (nwords ? nwords : 1) : 4096);
+    hipLaunchKernelGGL((fixup_kernel<MODE, N>), dim3(fgrid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -26,6 +26,6 @@ lib.fr_debug_read_stamps(buf, 1)
 plan.render(out.data_ptr(), W, H); ctx.sync()
 lib.fr_debug_read_stamps(buf, 1)
 v = np.array(list(buf), float)[:7]
-names = ["setup(cx,cy)", "phase0 cull+stage", "phase1 walk", "phase1 barrier wait", "phase1b zero+toggles", "barrier", "phase2 windows+stores"]
+names = ["setup (stage, cx table)", "phase1 walk (+cy)", "phase1b zero+toggles", "phase2 windows+stores", "-", "-", "-"]
 for nme, x in zip(names, v):
-    print(f"{nme:24s} {x / v.sum() * 100:6.2f} %   {x / (G * 4):10.0f} cycles/workgroup")
+    print(f"{nme:24s} {x / v.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup")
