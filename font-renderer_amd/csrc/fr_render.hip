@@ -189,7 +189,59 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             __syncthreads();
         }
         const uint32_t nchunk = min(256u, rec_cnt - base);
-        // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane
+        // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane.
+        // Neighbouring segments of a contour stack vertically, so consecutive records are live
+        // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
+        // broadcast) and the wave evaluates many records in ONE pass; a pass is flushed only
+        // when the next record wants a lane that is already taken.
+        float sa = 0.f, sb = 0.f, sc1 = 0.f, sc2 = 0.f, sax = 0.f, sbx = 0.f, sp0x = 0.f;
+        uint32_t sfl = 0;
+        bool taken = false;                     // this lane holds a latched record
+        unsigned long long occ = 0;             // lanes holding one (wave-uniform)
+        auto flush = [&]() {
+            if (taken) {
+                // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
+                const bool lin = (sfl & REC_LINEAR) != 0;
+                const float delta = cy * sa + sc1 - sc2;
+                const float sq = __builtin_sqrtf(delta);
+                const float num = lin ? (cy - sb) : ((sfl & REC_NEG_ROOT) ? (sb - sq) : (sb + sq));
+                const float t = num / (lin ? sc1 : sa);
+                const float xx = (sax * t + sbx) * t + sp0x;
+                const float dy = sa * t + (-sb);
+                const int sgn = lin ? ((sfl & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
+                // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
+                // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
+                // map, confirm with one paired read, walk only if the guess is off
+                float gf = xx * jscale - joff;
+                gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
+                int J = (int)gf;
+                {
+                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
+                    if (!(c0 <= xx && xx < c1)) {
+                        while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
+                        while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
+                    }
+                }
+                if (J > 0) {
+                    uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
+                    // sorted insert, registers only: compare-exchange chain, 8 slots at a
+                    // time; stop (wave-uniform) once every lane's carry is the EMPTY sentinel
+#pragma unroll
+                    for (int ch = 0; ch < CAP / 8; ++ch) {
+#pragma unroll
+                        for (int i = ch * 8; i < ch * 8 + 8; ++i) {
+                            const uint32_t mn = min(e[i], x);
+                            x = max(e[i], x);
+                            e[i] = mn;
+                        }
+                        if (__ballot(x != EMPTY) == 0ull) break;
+                    }
+                    if (x != EMPTY) ovf = true;
+                }
+            }
+            taken = false;
+            occ = 0;
+        };
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
             const Rec mine = s_rec[min(cb + lane, nchunk - 1u)];
             // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
@@ -199,46 +251,21 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float lo = bcast(mine.lo, k), hi = bcast(mine.hi, k);
-                if (row_valid && cy >= lo && cy <= hi) {
-                    Rec r;
-                    r.a = bcast(mine.a, k); r.b = bcast(mine.b, k); r.c1 = bcast(mine.c1, k);
-                    r.c2 = bcast(mine.c2, k); r.ax = bcast(mine.ax, k); r.bx = bcast(mine.bx, k);
-                    r.p0x = bcast(mine.p0x, k);
-                    r.flags = (uint32_t)__builtin_amdgcn_readlane((int)mine.flags, (int)k);
-                    float xx; int sgn;
-                    rec_cross(r, cy, xx, sgn);
-                    // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
-                    // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
-                    // map, confirm with one paired read, walk only if the guess is off
-                    float gf = xx * jscale - joff;
-                    gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
-                    int J = (int)gf;
-                    {
-                        const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
-                        if (!(c0 <= xx && xx < c1)) {
-                            while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
-                            while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
-                        }
-                    }
-                    if (J > 0) {
-                        uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
-                        // sorted insert, registers only: compare-exchange chain, 8 slots at a
-                        // time; stop (wave-uniform) once every lane's carry is the EMPTY sentinel
-#pragma unroll
-                        for (int ch = 0; ch < CAP / 8; ++ch) {
-#pragma unroll
-                            for (int i = ch * 8; i < ch * 8 + 8; ++i) {
-                                const uint32_t mn = min(e[i], x);
-                                x = max(e[i], x);
-                                e[i] = mn;
-                            }
-                            if (__ballot(x != EMPTY) == 0ull) break;
-                        }
-                        if (x != EMPTY) ovf = true;
-                    }
+                const bool want = row_valid && cy >= lo && cy <= hi;
+                const unsigned long long wl = __ballot(want);
+                if (!wl) continue;
+                if (wl & occ) flush();
+                if (want) {
+                    sa = bcast(mine.a, k); sb = bcast(mine.b, k); sc1 = bcast(mine.c1, k);
+                    sc2 = bcast(mine.c2, k); sax = bcast(mine.ax, k); sbx = bcast(mine.bx, k);
+                    sp0x = bcast(mine.p0x, k);
+                    sfl = (uint32_t)__builtin_amdgcn_readlane((int)mine.flags, (int)k);
+                    taken = true;
                 }
+                occ |= wl;
             }
         }
+        if (occ) flush();
     }
     STAMP(1);                                   // phase 1: record walk
     if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
