@@ -147,13 +147,14 @@ def main():
         orc.render_batch(gs, jobs[:probe], oracle_lib.COVERAGE_U8, buf, n, True, 1)
         per_glyph = (time.perf_counter() - t) / probe
         ng = int(max(threads, min(G, args.cpu_seconds * threads / max(per_glyph, 1e-9))))
-        ng = min(G, (ng // threads) * threads if ng >= threads else ng)
+        unit = max(threads, cols)                      # whole atlas rows, so the sample can be compared with the GPU's bytes
+        ng = min(G, (ng // unit) * unit if ng >= unit else ng)
         buf = np.zeros(atlas_shape(ng, cell, cols), np.uint8)
         t = time.perf_counter()
         orc.render_batch(gs, jobs[:ng], oracle_lib.COVERAGE_U8, buf, n, True, threads)
         ct = time.perf_counter() - t
         with torch.cuda.stream(stream):
-            same = bool(np.array_equal(out[:buf.shape[0]].cpu().numpy()[:, :], buf)) if ng % cols == 0 or ng <= cols else None
+            same = bool(np.array_equal(out[:buf.shape[0]].cpu().numpy(), buf)) if (ng % cols == 0 or ng <= cols) else None
         cpu = {"value": round(ng * cell * cell / ct / 1e6, 4), "unit": "Mpixel/s", "cores": threads, "kind": "port",
                "sample": f"first {ng} glyphs of the same workload ({cell}x{cell}, {n * n} samples/pixel), "
                          f"{ct:.1f} s wall on {threads} threads, oracle/fr_oracle.c (C restatement of "

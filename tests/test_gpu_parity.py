@@ -242,3 +242,26 @@ def test_full_size_properties_config3_shape(ctx):
     frac = (a > 0).mean()
     assert 0.2 < frac < 0.8
     plan.close(); dgs.close()
+
+
+def test_cpp_host_mirror(ctx, ascii_set, tmp_path):
+    """font-renderer_amd/host/fr_host.hpp (C++ mirror of renderGlyph / Image.Gray / windingInGlyph)
+    through the same C ABI: STIX 'A' at 64 -> 47x45, Appendix B histogram, same bytes as Python."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "font-renderer_amd", "host", "host_selftest")
+    i = ascii_set.find("STIX", "A")
+    gs1 = ascii_set.gs.subset(i, i + 1)
+    gs1.points_xy.astype("<i2").tofile(tmp_path / "pts.bin")
+    gs1.contour_start.astype("<u4").tofile(tmp_path / "cs.bin")
+    env = dict(os.environ, FR_HIP_RUNTIME="system")
+    out = subprocess.run([exe, str(tmp_path / "pts.bin"), str(tmp_path / "cs.bin")], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    w, h, hm2, hm1, h0, h1, fnv, wi = out.stdout.split()
+    assert (int(w), int(h), int(hm2), int(hm1), int(h0), int(h1)) == (47, 45, 1, 28, 1641, 445)
+    assert int(wi) == 0
+    gray = fr.renderGlyph(ascii_set.glyph(i), fr.FontInformation(1000), 64, ctx=ctx).data
+    hh = 1469598103934665603
+    for b in gray.tolist():
+        hh = ((hh ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(fnv, 16) == hh

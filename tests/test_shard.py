@@ -1,0 +1,77 @@
+"""CPU suite: the N > 1 path with world_size-2 gloo.
+
+Each rank owns a contiguous glyph range, renders ITS glyph subset into ITS atlas band (here
+with the oracle standing in for the GPU: the sharding/gather logic is what is under test),
+then one all_gather assembles the atlas.  The result must equal the unsharded render byte
+for byte.  No collective touches the render path itself."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, initfile, outdir, n_glyphs, cell, cols):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import oracle_lib
+    from font_renderer_amd.atlas import atlas_shape, cell_jobs
+    from font_renderer_amd.shard import gather_atlas, shard_range
+    from font_renderer_amd.synth import synth_glyphset
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.Oracle()
+        gs = synth_glyphset(n_glyphs, 24)
+        lo, hi = shard_range(n_glyphs, rank, world)
+        sub = gs.subset(lo, hi)                                  # only this rank's points travel to "its GPU"
+        jobs = cell_jobs(sub, cell, cell, 2048, cols)
+        band = np.zeros(atlas_shape(hi - lo, cell, cols), np.uint8)
+        orc.render_batch(sub, jobs, oracle_lib.COVERAGE_U8, band, 2, True)
+        full = gather_atlas(torch.from_numpy(band), n_glyphs, cell, cols)
+        np.save(os.path.join(outdir, f"rank{rank}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    from font_renderer_amd.shard import shard_ranges
+    for n in (0, 1, 7, 95, 20992, 63488):
+        for w in (1, 2, 3, 8):
+            r = shard_ranges(n, w)
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_two_rank_gloo_gather_equals_unsharded(oracle):
+    from font_renderer_amd.atlas import atlas_shape, cell_jobs
+    from font_renderer_amd.shard import shard_ranges
+    from font_renderer_amd.synth import synth_glyphset
+    n_glyphs, cell, cols, world = 22, 24, 4, 2          # 11 glyphs per rank: ragged last rows on both
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, initfile, d, n_glyphs, cell, cols), nprocs=world, join=True)
+        got = [np.load(os.path.join(d, f"rank{r}.npy")) for r in range(world)]
+    assert np.array_equal(got[0], got[1])
+    # expected: each rank's band is a cols-wide atlas of its own glyphs, bands stacked in rank order
+    import oracle_lib as O
+    gs = synth_glyphset(n_glyphs, 24)
+    bands = []
+    for lo, hi in shard_ranges(n_glyphs, world):
+        sub = gs.subset(lo, hi)
+        b = np.zeros(atlas_shape(hi - lo, cell, cols), np.uint8)
+        oracle.render_batch(sub, cell_jobs(sub, cell, cell, 2048, cols), O.COVERAGE_U8, b, 2, True)
+        bands.append(b)
+    assert np.array_equal(got[0], np.concatenate(bands, 0))
+    # and a glyph rendered inside a shard equals the same glyph rendered unsharded
+    whole = np.zeros(atlas_shape(n_glyphs, cell, cols), np.uint8)
+    oracle.render_batch(gs, cell_jobs(gs, cell, cell, 2048, cols), O.COVERAGE_U8, whole, 2, True)
+    assert np.array_equal(whole[:cell, :cell], got[0][:cell, :cell])
+    lo1 = shard_ranges(n_glyphs, world)[1][0]
+    r1_row0 = atlas_shape(lo1, cell, cols)[0]
+    gy, gx = (lo1 // cols) * cell, (lo1 % cols) * cell
+    assert np.array_equal(whole[gy:gy + cell, gx:gx + cell], got[0][r1_row0:r1_row0 + cell, :cell])
