@@ -59,6 +59,7 @@ SYMBOLS = [
     ("fr_glyph_info_init", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("fr_winding_in_glyph", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     ("fr_winding_lattice", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    ("fr_selftest_division", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 
 _lib = None

@@ -27,8 +27,26 @@ namespace fr {
 //   Ax = (p0x - 2*p1x) + p2x, Bx = 2*(p1x - p0x)               (:53, :65)
 struct __attribute__((aligned(16))) Rec {
     float lo, hi, a, b, c1, c2, ax, bx, p0x;
-    uint32_t flags, pad0, pad1;
+    uint32_t flags;
+    float rden;          // RN(1 / d), d = the divisor of t: a (quadratic) or p2y - p0y (linear)
+    uint32_t pad1;
 };
+
+// x / d for an INTEGER divisor |d| <= 2^17 with rd = RN(1/d): Markstein's correction
+//   q = RN(x*rd); r = x - q*d (exact in one FMA); q' = RN(q + r*rd)
+// returns the correctly rounded quotient — bit-identical to IEEE division — for every binary32
+// x whose quotient and residual stay normal.  Not taken on trust: fr_selftest_division
+// (fr_selftest.hip) compares it with hipcc's IEEE `/` for ALL 2^23 significands x EVERY integer
+// divisor 1..2^17 on the GPU; the exponent of x is irrelevant (scaling by 2^k is exact) as long
+// as nothing leaves the normal range, which fr_plan_create guarantees by bounding `scale`
+// (DESIGN.md §3.4).  The FMAs here implement a division; they are not a contraction of the
+// reference's expression.
+__device__ __forceinline__ float div_by_int(float x, float d, float rd)
+{
+    const float q = x * rd;
+    const float r = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(r, rd, q);
+}
 enum : uint32_t {
     REC_LINEAR = 1u,     // a == 0 branch
     REC_NEG_ROOT = 2u,   // t- = (B - sqrt(delta)) / a ; otherwise t+

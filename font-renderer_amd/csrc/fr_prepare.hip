@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
         const uint32_t c = base + lane;
         bool valid = false;
         Rec r;
-        r.pad0 = 0; r.pad1 = 0;
+        r.rden = 0.0f; r.pad1 = 0;
         float lo = 0.f, hi = 0.f;
         if (c < n_cand) {
             const uint32_t s = s0 + (c >> 1);
@@ -132,11 +132,13 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
             if (a == 0.0f) {                                     // :49
                 if (root == 0u && p2y != p0y) {                  // :50
                     r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
+                    r.rden = 1.0f / r.c1;
                     r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
                     valid = true;
                 }
             } else {
                 r.a = a; r.b = p0y - p1y; r.c1 = p1y * p1y; r.c2 = p0y * p2y;    // :58, :60
+                r.rden = 1.0f / a;
                 r.flags = root ? REC_NEG_ROOT : 0u;
                 valid = true;
             }

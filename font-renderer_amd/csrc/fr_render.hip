@@ -79,9 +79,11 @@ __device__ unsigned long long g_stamps[8];
 #define STAMP_INIT()                                                                      \
     unsigned long long t_prev_;                                                           \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_)::"memory")
+#define COUNT(i, n) do { if (lane == 0) atomicAdd(&g_stamps[i], (unsigned long long)(n)); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #define STAMP_INIT() do {} while (0)
+#define COUNT(i, n) do {} while (0)
 #endif
 
 // LDS line of sample row r (0..31 of a half band) in a wave's window-mask array.  Swapping
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
         // broadcast) and the wave evaluates many records in ONE pass; a pass is flushed only
         // when the next record wants a lane that is already taken.
-        float sa = 0.f, sb = 0.f, sc1 = 0.f, sc2 = 0.f, sax = 0.f, sbx = 0.f, sp0x = 0.f;
+        float sa = 0.f, sb = 0.f, sc1 = 0.f, sc2 = 0.f, sax = 0.f, sbx = 0.f, sp0x = 0.f, srd = 0.f;
         uint32_t sfl = 0;
         bool taken = false;                     // this lane holds a latched record
         unsigned long long occ = 0;             // lanes holding one (wave-uniform)
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const float delta = cy * sa + sc1 - sc2;
                 const float sq = __builtin_sqrtf(delta);
                 const float num = lin ? (cy - sb) : ((sfl & REC_NEG_ROOT) ? (sb - sq) : (sb + sq));
-                const float t = num / (lin ? sc1 : sa);
+                const float t = div_by_int(num, lin ? sc1 : sa, srd);      // == num / d, see fr_device.hpp
                 const float xx = (sax * t + sbx) * t + sp0x;
                 const float dy = sa * t + (-sb);
                 const int sgn = lin ? ((sfl & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
@@ -254,19 +256,22 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const bool want = row_valid && cy >= lo && cy <= hi;
                 const unsigned long long wl = __ballot(want);
                 if (!wl) continue;
-                if (wl & occ) flush();
+                COUNT(5, 1);                    // records that touch the wave
+                COUNT(7, __popcll(wl));         // lanes they are live on
+                if (wl & occ) { COUNT(6, 1); flush(); }
                 if (want) {
                     sa = bcast(mine.a, k); sb = bcast(mine.b, k); sc1 = bcast(mine.c1, k);
                     sc2 = bcast(mine.c2, k); sax = bcast(mine.ax, k); sbx = bcast(mine.bx, k);
-                    sp0x = bcast(mine.p0x, k);
+                    sp0x = bcast(mine.p0x, k); srd = bcast(mine.rden, k);
                     sfl = (uint32_t)__builtin_amdgcn_readlane((int)mine.flags, (int)k);
                     taken = true;
                 }
                 occ |= wl;
             }
         }
-        if (occ) flush();
+        if (occ) { COUNT(6, 1); flush(); }
     }
+    COUNT(4, 1);                                // wave bands
     STAMP(1);                                   // phase 1: record walk
     if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):

@@ -165,6 +165,15 @@ int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *c
 int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                        uint32_t n_contours, const int16_t box[4], int16_t *out_host);
 
+/* ---- self-test: exhaustive device-side check of an arithmetic shortcut ----------
+ * The render kernel computes t = num / d (render_glyph.zig:51,60-61; d an integer, |d| <= 2^17)
+ * as a reciprocal multiply + FMA correction.  This compares that sequence with IEEE division
+ * for EVERY binary32 significand and every integer divisor in [d_lo, d_hi] (both signs, three
+ * binades) on the current HIP device; *mismatches must come back 0 for the shortcut to be
+ * admissible.  The full range 1..131072 takes a few seconds.                              */
+int fr_selftest_division(uint32_t d_lo, uint32_t d_hi, uint64_t *mismatches,
+                         uint32_t *bad_divisor, uint32_t *bad_x_bits);
+
 #ifdef __cplusplus
 }
 #endif

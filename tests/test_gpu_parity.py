@@ -265,3 +265,15 @@ def test_cpp_host_mirror(ctx, ascii_set, tmp_path):
     for b in gray.tolist():
         hh = ((hh ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert int(fnv, 16) == hh
+
+
+def test_division_shortcut_is_exact_exhaustively(ctx):
+    """div_by_int (reciprocal multiply + Markstein FMA correction) == IEEE x / d for ALL 2^23
+    significands x every integer divisor 1..2^17, both signs, three binades — run on the device.
+    This is the proof obligation for using it in place of render_glyph.zig:51,60-61's `/`."""
+    import ctypes as C
+    from font_renderer_amd import _lib
+    lib = _lib.load_library()
+    m, bd, bx = C.c_uint64(1), C.c_uint32(), C.c_uint32()
+    _lib.check(lib.fr_selftest_division(1, 1 << 17, C.byref(m), C.byref(bd), C.byref(bx)))
+    assert m.value == 0, f"{m.value} mismatches, e.g. divisor {bd.value}, x bits {bx.value:#x}"

@@ -25,7 +25,10 @@ plan.render(out.data_ptr(), W, H); ctx.sync()
 lib.fr_debug_read_stamps(buf, 1)
 plan.render(out.data_ptr(), W, H); ctx.sync()
 lib.fr_debug_read_stamps(buf, 1)
-v = np.array(list(buf), float)[:7]
+v = np.array(list(buf), float)
 names = ["setup (stage, cx table)", "phase1 walk (+cy)", "phase1b zero+toggles", "phase2 windows+stores", "-", "-", "-"]
-for nme, x in zip(names, v):
-    print(f"{nme:24s} {x / v.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup")
+v4 = v[:4]
+for nme, x in zip(names, v4):
+    print(f"{nme:24s} {x / v4.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup")
+c = np.array(list(buf), float)
+print(f"wave bands {c[4]:.0f}; per wave band: records touching {c[5] / c[4]:.2f}, evaluation passes {c[6] / c[4]:.2f}, live lanes per record {c[7] / max(c[5], 1):.1f}")
