@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libfr_raster.so")
+    # FR_RASTER_LIB: diagnostic builds only (stamps / ablation); the product is libfr_raster.so
+    return os.environ.get("FR_RASTER_LIB") or os.path.join(_HERE, "libfr_raster.so")
 
 
 class FrError(RuntimeError):

@@ -106,19 +106,26 @@ __device__ __forceinline__ float rec_t_lin(const Rec &r, float cy)
 {
     return (cy - r.b) / r.c1;
 }
-// x of the crossing and the sign it adds (:53-55, :65-68)
-__device__ __forceinline__ void rec_cross(const Rec &r, float cy, float &xx, int &sgn)
+// the reference's decision for one record at ray height cy (:49-69): is the root accepted,
+// where does it cross (xx) and which sign does it add.  [lo, hi] only brackets the accepted
+// set, so the three rejection tests (:52, :59, :64) are applied here exactly as written.
+__device__ __forceinline__ bool rec_cross(const Rec &r, float cy, float &xx, int &sgn)
 {
     float t;
+    bool ok;
     if (r.flags & REC_LINEAR) {
         t = rec_t_lin(r, cy);
+        ok = !(t < 0.0f || t >= 1.0f);                                  // :52
         sgn = (r.flags & REC_LIN_MINUS) ? -1 : 1;
     } else {
+        const float delta = cy * r.a + r.c1 - r.c2;                     // :58
         t = rec_t_quad(r, cy);
+        ok = !(delta < 0.0f) && !(t < 0.0f || t >= 1.0f);               // :59, :64
         float dy = r.a * t + (-r.b);           // a*t + (p1y - p0y), :67
         sgn = (dy > 0.0f) ? -1 : 1;            // :68
     }
     xx = (r.ax * t + r.bx) * t + r.p0x;        // :53 / :65
+    return ok;
 }
 
 // sub-sample offset (k + phase)/n — exact in binary32 for n in {1,2,4}

@@ -1,22 +1,23 @@
-// fr_prepare.hip — per-segment precompute: root records with EXACT acceptance intervals.
+// fr_prepare.hip — per-segment precompute: root records with GUARANTEED acceptance brackets.
 //
-// Why an interval is exact.  For one root of one segment the reference decides
-// "accept" from (render_glyph.zig:58-64)
+// Why a bracket is sound.  For one root of one segment the reference decides "accept" from
+// (render_glyph.zig:58-64)
 //        delta = fl(fl(fl(cy*a) + c1) - c2);   reject if delta < 0
 //        t     = fl(fl(B +/- sqrt(delta)) / a); reject if t < 0 or t >= 1
-// with a, B, c1, c2 constants of the segment.  Every step is a correctly rounded
-// IEEE operation with one varying operand, hence a monotone function of it; so
-// delta(cy) is monotone (direction = sign a), sqrt is non-decreasing, and
-// t+(cy) is non-decreasing / t-(cy) non-increasing for either sign of a.  The
-// three rejection tests are therefore each a one-sided cut of the cy axis, and the
-// accepted set is a closed interval [lo, hi] of binary32 values.  We locate its two
-// ends by searching the ordered bit patterns of ALL finite floats (exponential search out
-// of analytic hints, then bisection), evaluating the reference's own expression
-// (rec_t_quad / rec_t_lin) at each probe — no error analysis, no tolerance: the hints
-// only decide where the search starts, never what it returns.  The same holds for the a == 0 branch (:51-52).
-// With [lo, hi] known the render kernel tests  lo <= cy <= hi  (two compares) instead
-// of solving the quadratic for every (row, segment), and rows outside it are culled
-// with a bit-exact guarantee.
+// with a, B, c1, c2 constants of the segment.  Every step is a correctly rounded IEEE
+// operation with one varying operand, hence a monotone function of it; so delta(cy) is
+// monotone (direction = sign a), sqrt is non-decreasing, and t+(cy) is non-decreasing /
+// t-(cy) non-increasing for either sign of a.  The three rejection tests are therefore each a
+// one-sided cut of the cy axis: classify() below is a monotone step function 0 -> 1 -> 2
+// ("below the accepted set", "accepted", "above it") over the ordered binary32 values.
+// Consequently ONE probe with class 0 proves that every smaller cy is rejected, and one probe
+// with class 2 proves the same for every larger cy.  We probe the three heights where the
+// cuts sit in exact arithmetic (t = 0 at p0y, t = 1 at p2y, delta = 0 at the vertex) and a few
+// rounding-plateau widths either side of them, evaluating the reference's own expression, and
+// keep  lo = just above the highest class-0 probe,  hi = just below the lowest class-2 probe.
+// [lo, hi] CONTAINS the accepted set (exactly, not approximately); the render kernel culls
+// with it and still applies the reference's own three tests to whatever survives, so the
+// bracket only ever saves work.  The same holds for the a == 0 branch (:51-52).
 #include "fr_device.hpp"
 
 namespace fr {
@@ -42,17 +43,15 @@ __device__ __forceinline__ int classify(const Rec &r, float cy)
 
 // Smallest key k in [L, H] such that class(k) >= T, given the invariant
 //   every key <  L has class <  T,   every key >= H has class >= T      (class is monotone).
-// Two-sided exponential search, then bisection: the cut almost always sits a few ulps
-// from one end of the bracket (the ends are the segment's p0y / p2y / vertex height),
-// so this takes ~2*log2(distance) probes instead of 32.
-__device__ inline uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint32_t H)
+// Only used when the cheap probes leave a side unbounded (rare): exponential, then bisection.
+__device__ __noinline__ uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint32_t H)
 {
     uint32_t step = 1u;
     while (step < (1u << 30) && H - L > 2u * step) {
-        const uint32_t pl = L + step - 1u;                  // probe near the low end
+        const uint32_t pl = L + step - 1u;
         if (classify(r, key2f(pl)) >= T) { H = pl; break; }
         L = pl + 1u;
-        const uint32_t ph = H - step;                       // probe near the high end (ph >= L here)
+        const uint32_t ph = H - step;
         if (classify(r, key2f(ph)) < T) { L = ph + 1u; break; }
         H = ph;
         step <<= 1;
@@ -64,38 +63,52 @@ __device__ inline uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint3
     return L;
 }
 
-__device__ inline bool accept_interval(const Rec &r, float p0y, float p2y, float &lo, float &hi)
+__device__ inline bool accept_bracket(const Rec &r, float p0y, float p2y, float &lo, float &hi)
 {
     const uint32_t kmin = f2key(-3.402823466e+38f), kmax = f2key(3.402823466e+38f);
-    // bracket both cuts with the three heights where they can sit in exact arithmetic:
-    // t = 0 at cy = p0y, t = 1 at cy = p2y, delta = 0 at the parabola's vertex height
-    // y(t) = p0y - 2 B t + a t^2, t_v = B / a
+    // LB: every key < LB is class 0.  HB: every key >= HB is class 2.
+    uint32_t LB = kmin, HB = kmax + 1u;
+    bool seen1 = false;
+    auto probe = [&](float c) {
+        if (!(c >= -3.402823466e+38f && c <= 3.402823466e+38f)) return;      // hints only
+        const uint32_t k = f2key(c);
+        const int cl = classify(r, c);
+        if (cl == 0) { if (k + 1u > LB) LB = k + 1u; }
+        else if (cl == 2) { if (k < HB) HB = k; }
+        else seen1 = true;
+    };
+    // width of one rounding plateau of cy*a + c1 near the glyph: ulp(max|c1|,|c2|) / |a|
+    float w = 0.0f;
     float cand[3];
     int ncand = 2;
     cand[0] = p0y; cand[1] = p2y;
-    if (!(r.flags & REC_LINEAR)) { cand[2] = p0y - (r.b * r.b) / r.a; ncand = 3; }
-    uint32_t L1 = kmin, H1 = kmax + 1u, L2 = kmin, H2 = kmax + 1u;
-    for (int i = 0; i < ncand; ++i) {
-        float c = cand[i];
-        if (!(c >= -3.402823466e+38f && c <= 3.402823466e+38f)) continue;   // hints only
-        const uint32_t k = f2key(c);
-        const int cl = classify(r, c);
-        if (cl >= 1) { if (k < H1) H1 = k; } else { if (k + 1u > L1) L1 = k + 1u; }
-        if (cl >= 2) { if (k < H2) H2 = k; } else { if (k + 1u > L2) L2 = k + 1u; }
+    if (!(r.flags & REC_LINEAR)) {
+        cand[2] = p0y - (r.b * r.b) / r.a;                                    // vertex: y(B/a)
+        ncand = 3;
+        const float big = fmaxf(fmaxf(fabsf(r.c1), fabsf(r.c2)), 1.0f);
+        w = (big * 1.1920929e-07f) / fabsf(r.a);                              // ~ulp(big)/|a|
     }
-    const uint32_t first = first_at_least(r, 1, L1, H1);    // first accepted key
-    if (L2 < first) L2 = first;                             // class 2 cannot start below it
-    if (H2 < L2) H2 = L2;
-    const uint32_t a = first_at_least(r, 2, L2, H2);        // first key above the interval
-    if (a == kmin || first > a - 1u) return false;
-    lo = key2f(first);
-    hi = key2f(a - 1u);
+    for (int i = 0; i < ncand; ++i) {
+        const float c = cand[i];
+        const float d = fmaxf(4.0f * w, fabsf(c) * 4.76837158e-07f);          // >= 4 plateaus, >= 4 ulp
+        probe(c - d);
+        probe(c);
+        probe(c + d);
+    }
+    if (LB >= HB) return false;                          // class 0 up to LB-1, class 2 from HB: never accepted
+    // a side the probes did not bound (no class-0 / class-2 probe at all): settle it exactly
+    if (LB == kmin) LB = first_at_least(r, 1, kmin, HB);
+    if (HB == kmax + 1u) HB = first_at_least(r, 2, LB, kmax + 1u);
+    if (LB >= HB) return false;
+    (void)seen1;
+    lo = key2f(LB);
+    hi = key2f(HB - 1u);
     return true;
 }
 
 // One wave64 per glyph.  Lane l builds candidate record c = base + l, where
 // candidate 2s / 2s+1 are the t+ / t- roots of segment s (2s alone for a == 0);
-// survivors are compacted with a ballot + prefix popcount into the glyph's slice
+// survivors (records whose bracket is not provably empty) are compacted with a ballot + prefix popcount into the glyph's slice
 // [2*seg_start[g], ...) of the record arrays.
 __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__ pts,
                                                      const uint32_t *__restrict__ seg_p0,
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
                 r.flags = root ? REC_NEG_ROOT : 0u;
                 valid = true;
             }
-            if (valid) valid = accept_interval(r, p0y, p2y, lo, hi);
+            if (valid) valid = accept_bracket(r, p0y, p2y, lo, hi);
         }
         const unsigned long long m = __ballot(valid);
         if (valid) {

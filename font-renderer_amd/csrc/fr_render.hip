@@ -42,8 +42,7 @@ __device__ __noinline__ int brute_winding(const Rec *__restrict__ recs, uint32_t
         const Rec r = recs[c];
         if (cy >= r.lo && cy <= r.hi) {
             float xx; int sgn;
-            rec_cross(r, cy, xx, sgn);
-            if (!(xx < cx)) w += sgn;
+            if (rec_cross(r, cy, xx, sgn) && !(xx < cx)) w += sgn;
         }
     }
     return w;
@@ -208,6 +207,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const float sq = __builtin_sqrtf(delta);
                 const float num = lin ? (cy - sb) : ((sfl & REC_NEG_ROOT) ? (sb - sq) : (sb + sq));
                 const float t = div_by_int(num, lin ? sc1 : sa, srd);      // == num / d, see fr_device.hpp
+                // [lo, hi] brackets the accepted set; the reference's own tests decide (:52, :59, :64)
+                const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
                 const float xx = (sax * t + sbx) * t + sp0x;
                 const float dy = sa * t + (-sb);
                 const int sgn = lin ? ((sfl & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                         while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
                     }
                 }
-                if (J > 0) {
+                if (accepted && J > 0) {
                     uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
                     // sorted insert, registers only: compare-exchange chain, 8 slots at a
                     // time; stop (wave-uniform) once every lane's carry is the EMPTY sentinel
