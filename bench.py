@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kmax", type=int, default=0, help="crossings per sample row kept in registers (8/16/32)")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (experiments)")
     ap.add_argument("--no-prep-in-step", action="store_true", help="time the render kernel alone per step")
     args = ap.parse_args()
 
@@ -75,6 +76,9 @@ def main():
     ctx = fr.Context(local, stream.cuda_stream)
     if args.kmax:
         ctx.set_option("kmax", args.kmax)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     with torch.cuda.stream(stream):
         out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     dgs = fr.DeviceGlyphSet(ctx, gs)                       # points -> HBM (+ first precompute)

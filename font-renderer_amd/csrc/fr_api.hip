@@ -53,6 +53,7 @@ struct fr_ctx {
     bool owns_stream = false;
     uint32_t kmax = 32;          // crossings kept per sample row (register array: 8, 16 or 32) before the direct-sum fallback
     uint32_t strip_px = 256;     // column strip width, pixels (multiple of 16, <= 256)
+    uint32_t lds_pad = 0;        // experiment knob: extra dynamic LDS bytes per workgroup (occupancy studies)
     uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
 };
 
@@ -139,6 +140,7 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
         ctx->strip_px = (uint32_t)value;
         return FR_OK;
     }
+    if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
     if (!strcmp(key, "min_wgs")) {
         if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
         ctx->min_wgs = (uint32_t)value;
@@ -377,7 +379,8 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
-    a.nwin_log = 0; a.lds_region = 0; a.lds_wave_bytes = 0; a.lds_tail = 0;
+    a.lds_pad = plan->ctx->lds_pad;
+    a.nwin_log = 0; a.lds_region = 0; a.lds_rec_bytes = 0; a.lds_wave_bytes = 0; a.lds_tail = 0;
     // one workgroup walks all bands of its cell (cx table, job and records staged once)
     // unless the batch is too small to fill the chip: then split the bands over workgroups
     // (bands are wave bands of 64/n pixel rows; a workgroup's 4 waves take them round-robin)

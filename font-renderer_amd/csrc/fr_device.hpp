@@ -74,7 +74,8 @@ struct RenderArgs {
     uint32_t n_jobs, bands, strips, strip_w, kmax;
     uint32_t bands_per_wg, band_groups;   // a workgroup walks bands_per_wg consecutive bands of its cell
     int32_t phase_center;
-    uint32_t nwin_log, lds_region, lds_wave_bytes, lds_tail;   // filled by launch_render (LDS plan)
+    uint32_t lds_pad;
+    uint32_t nwin_log, lds_region, lds_rec_bytes, lds_wave_bytes, lds_tail;   // filled by launch_render (LDS plan)
 };
 
 // order-preserving map binary32 -> u32 (total order, -0 < +0)

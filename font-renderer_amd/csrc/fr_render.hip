@@ -59,7 +59,31 @@ __device__ __forceinline__ float bcast(float v, uint32_t k)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)k));
 }
 
+#ifndef FR_BAND_PARTS
+#define FR_BAND_PARTS 2
+#endif
 constexpr uint32_t EMPTY = 0xffffffffu;
+// records staged in LDS per pass, packed to 11 dwords (the 48-byte global record minus its pad):
+// 256 x 44 B keeps a C3-shaped workgroup at 32 272 B of LDS — FIVE workgroups per CU, not four —
+// and an 11-dword stride is bank-conflict-free for one-record-per-lane reads
+constexpr uint32_t RCHUNK = 256u;
+constexpr uint32_t RWORDS = 11u;
+__device__ __forceinline__ void rec_to_lds(uint32_t *dst, const Rec &r)
+{
+    dst[0] = __float_as_uint(r.lo); dst[1] = __float_as_uint(r.hi); dst[2] = __float_as_uint(r.a);
+    dst[3] = __float_as_uint(r.b); dst[4] = __float_as_uint(r.c1); dst[5] = __float_as_uint(r.c2);
+    dst[6] = __float_as_uint(r.ax); dst[7] = __float_as_uint(r.bx); dst[8] = __float_as_uint(r.p0x);
+    dst[9] = r.flags; dst[10] = __float_as_uint(r.rden);
+}
+__device__ __forceinline__ Rec rec_from_lds(const uint32_t *src)
+{
+    Rec r;
+    r.lo = __uint_as_float(src[0]); r.hi = __uint_as_float(src[1]); r.a = __uint_as_float(src[2]);
+    r.b = __uint_as_float(src[3]); r.c1 = __uint_as_float(src[4]); r.c2 = __uint_as_float(src[5]);
+    r.ax = __uint_as_float(src[6]); r.bx = __uint_as_float(src[7]); r.p0x = __uint_as_float(src[8]);
+    r.flags = src[9]; r.rden = __uint_as_float(src[10]); r.pad1 = 0;
+    return r;
+}
 
 // Diagnostic build only (make STAMPS=1 -> libfr_raster_stamps.so): per-phase shader-clock
 // sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
@@ -104,7 +128,9 @@ template <int MODE, int N, int CAP>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
     constexpr uint32_t WBAND = 64u / N;         // pixel rows per wave band (64 sample rows)
-    constexpr uint32_t HROWS = 32u / N;         // pixel rows per half band (32 sample rows)
+    constexpr uint32_t PARTS = FR_BAND_PARTS;   // 1: whole band at once (8 KB of masks per wave); 2: two half bands (4 KB)
+    constexpr uint32_t PROWS_S = 64u / PARTS;   // sample rows per part
+    constexpr uint32_t HROWS = PROWS_S / N;     // pixel rows per part
     constexpr int WCOLS = 16 * N;               // sample columns per 16-pixel window (<= 64)
     constexpr int WSHIFT = (N == 4) ? 6 : (N == 2 ? 5 : 4);
     constexpr unsigned long long WALL = (N == 4) ? ~0ull : ((1ull << WCOLS) - 1ull);
@@ -136,15 +162,15 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
     // s_cxp[0] = -inf, s_cxp[1 + j] = cx(j), s_cxp[1 + ncol] = +inf
     float *s_cxp = reinterpret_cast<float *>(smem);
-    Rec *s_rec = reinterpret_cast<Rec *>(smem + A.lds_region);
-    unsigned char *wregion = smem + A.lds_region + 256 * sizeof(Rec) + (size_t)wave * A.lds_wave_bytes;
+    uint32_t *s_rec = reinterpret_cast<uint32_t *>(smem + A.lds_region);               // [RCHUNK][RWORDS]
+    unsigned char *wregion = smem + A.lds_region + A.lds_rec_bytes + (size_t)wave * A.lds_wave_bytes;
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(wregion);    // [32][nwin_pad]
     uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
-    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * 32u; // [32]
+    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * PROWS_S; // [PROWS_S]
 
     // stage the first (usually only) 256-record chunk: one record per lane, issued first so the
     // latency hides under the cx-table divisions
-    if (tid < rec_cnt) s_rec[tid] = grec[tid];
+    if (tid < min(rec_cnt, RCHUNK)) rec_to_lds(s_rec + tid * RWORDS, grec[tid]);
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
@@ -183,13 +209,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     for (int i = 0; i < CAP; ++i) e[i] = EMPTY;
     bool ovf = false;
 
-    for (uint32_t base = 0; base < rec_cnt; base += 256u) {
-        if (rec_cnt > 256u) {                   // multi-chunk glyph: restage (workgroup-uniform path)
+    for (uint32_t base = 0; base < rec_cnt; base += RCHUNK) {
+        if (rec_cnt > RCHUNK) {                   // multi-chunk glyph: restage (workgroup-uniform path)
             __syncthreads();
-            if (base + tid < rec_cnt) s_rec[tid] = grec[base + tid];
+            if (tid < RCHUNK && base + tid < rec_cnt) rec_to_lds(s_rec + tid * RWORDS, grec[base + tid]);
             __syncthreads();
         }
-        const uint32_t nchunk = min(256u, rec_cnt - base);
+        const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane.
         // Neighbouring segments of a contour stack vertically, so consecutive records are live
         // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             occ = 0;
         };
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
-            const Rec mine = s_rec[min(cb + lane, nchunk - 1u)];
+            const Rec mine = rec_from_lds(s_rec + min(cb + lane, nchunk - 1u) * RWORDS);
             // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
             // scalar find-first-set loop — records that miss the wave cost nothing
             unsigned long long todo = __ballot((cb + lane < nchunk) && (mine.hi >= wcy_bot) && (mine.lo <= wcy_top));
@@ -285,10 +311,10 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 
     // ---- phases 1b + 2, one half band (32 sample rows) at a time, wave-private LDS
 #pragma unroll
-    for (uint32_t half = 0; half < 2u; ++half) {
-        if (half * 32u >= nrows) break;                             // wave-uniform
-        const bool mine_half = (lane >> 5) == half;
-        const uint32_t hrow = lane & 31u;                           // my row inside the half
+    for (uint32_t half = 0; half < PARTS; ++half) {
+        if (half * PROWS_S >= nrows) break;                         // wave-uniform
+        const bool mine_half = (PARTS == 1u) || ((lane >> 5) == half);
+        const uint32_t hrow = lane & (PROWS_S - 1u);                // my row inside the part
         const uint32_t prow0 = y0 + half * HROWS;                   // first pixel row of the half
         const uint32_t prows = min(HROWS, job.h - prow0);           // pixel rows in the half
         const size_t out_row0 = (size_t)job.out_y + prow0;
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             // zero the half's masks cooperatively (consecutive 16-B stores: no bank conflicts)
             {
                 uint4 *z = reinterpret_cast<uint4 *>(wregion);
-                for (uint32_t q = lane; q < (16u << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
+                for (uint32_t q = lane; q < ((PROWS_S / 2u) << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
             }
             wave_lds_sync();
             // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity
@@ -525,25 +551,29 @@ __global__ __launch_bounds__(256) void fixup_kernel(const RenderArgs A)
     }
 }
 
-// LDS plan: padded cx table | staged records [256] | 4 x per-wave half-band region (window
+// LDS plan: padded cx table | staged records [RCHUNK] | 4 x per-wave half-band region (window
 // masks [32][nwin_pad] u64, or breakpoint rows [32][CAP] u32) | 4 x fill[32]
 void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *nwin_log,
-                     uint32_t *region, uint32_t *wave_bytes, uint32_t *tail, size_t *total)
+                     uint32_t *region, uint32_t *rec_bytes, uint32_t *wave_bytes, uint32_t *tail, size_t *total)
 {
     uint32_t nwin = (strip_w + 15u) / 16u, lg = 0;
     while ((1u << lg) < nwin) ++lg;
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
-    const size_t wb = mode == MODE_COVERAGE_U8 ? (size_t)32 * (8u << lg) : (size_t)32 * cap * 4;
-    const size_t t = cx + 256 * sizeof(Rec) + 4 * wb;
+    const size_t prow = 64u / FR_BAND_PARTS;
+    const size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
+    const size_t rb = ((size_t)RCHUNK * RWORDS * 4 + 15) & ~(size_t)15;
+    const size_t t = cx + rb + 4 * wb;
+    *rec_bytes = (uint32_t)rb;
     *nwin_log = lg; *region = (uint32_t)cx; *wave_bytes = (uint32_t)wb; *tail = (uint32_t)t;
-    *total = t + 4 * 32 * 4;
+    *total = t + 4 * prow * 4;
 }
 
 template <int MODE, int N, int CAP>
 static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 {
     size_t lds;
-    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_wave_bytes, &a.lds_tail, &lds);
+    render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_rec_bytes, &a.lds_wave_bytes, &a.lds_tail, &lds);
+    lds += a.lds_pad;
     auto kern = render_kernel<MODE, N, CAP>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
