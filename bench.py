@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kmax", type=int, default=0, help="crossings per sample row kept in registers (8/16/32)")
+    ap.add_argument("--n", type=int, default=0, help="override samples per axis (experiments)")
+    ap.add_argument("--segs", type=int, default=0, help="override segments per glyph (experiments)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (experiments)")
     ap.add_argument("--no-prep-in-step", action="store_true", help="time the render kernel alone per step")
     args = ap.parse_args()
@@ -65,6 +67,10 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.glyphs:
         wl["glyphs"] = args.glyphs
+    if args.n:
+        wl["n"] = args.n
+    if args.segs:
+        wl["segs"] = args.segs
     G, cell, S, n, cols = wl["glyphs"], wl["cell"], wl["segs"], wl["n"], wl["cols"]
 
     # ---- inputs: this rank's glyph range (weak scaling: G glyphs per GPU)

@@ -62,29 +62,31 @@ __device__ __forceinline__ float bcast(float v, uint32_t k)
 #ifndef FR_BAND_PARTS
 #define FR_BAND_PARTS 2
 #endif
-constexpr uint32_t EMPTY = 0xffffffffu;
-// records staged in LDS per pass, packed to 11 dwords (the 48-byte global record minus its pad):
-// 256 x 44 B keeps a C3-shaped workgroup at 32 272 B of LDS — FIVE workgroups per CU, not four —
-// and an 11-dword stride is bank-conflict-free for one-record-per-lane reads
-constexpr uint32_t RCHUNK = 256u;
-constexpr uint32_t RWORDS = 11u;
-__device__ __forceinline__ void rec_to_lds(uint32_t *dst, const Rec &r)
-{
-    dst[0] = __float_as_uint(r.lo); dst[1] = __float_as_uint(r.hi); dst[2] = __float_as_uint(r.a);
-    dst[3] = __float_as_uint(r.b); dst[4] = __float_as_uint(r.c1); dst[5] = __float_as_uint(r.c2);
-    dst[6] = __float_as_uint(r.ax); dst[7] = __float_as_uint(r.bx); dst[8] = __float_as_uint(r.p0x);
-    dst[9] = r.flags; dst[10] = __float_as_uint(r.rden);
-}
-__device__ __forceinline__ Rec rec_from_lds(const uint32_t *src)
-{
-    Rec r;
-    r.lo = __uint_as_float(src[0]); r.hi = __uint_as_float(src[1]); r.a = __uint_as_float(src[2]);
-    r.b = __uint_as_float(src[3]); r.c1 = __uint_as_float(src[4]); r.c2 = __uint_as_float(src[5]);
-    r.ax = __uint_as_float(src[6]); r.bx = __uint_as_float(src[7]); r.p0x = __uint_as_float(src[8]);
-    r.flags = src[9]; r.rden = __uint_as_float(src[10]); r.pad1 = 0;
-    return r;
-}
+// One crossing = 16 bits: (J << 1) | (sign > 0), J <= 2048 sample columns; 0xffff = no crossing.
+constexpr uint32_t EMPTY = 0xffffu;
+constexpr uint32_t LSTRIDE = 40u;              // u16 slots per row list: 32 used + pad; an 80-byte
+                                               // row stride makes one-row-per-lane b128 reads conflict-free
 
+// Batcher's odd-even merge sort as a fixed compare-exchange network over registers (ascending).
+template <int NN>
+__device__ __forceinline__ void sort_network(uint32_t (&e)[32])
+{
+#pragma unroll
+    for (int p = 1; p < NN; p *= 2)
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (int j = k % p; j + k < NN; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; ++i)
+                    if (i + j + k < NN && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const uint32_t lo = min(e[i + j], e[i + j + k]);
+                        e[i + j + k] = max(e[i + j], e[i + j + k]);
+                        e[i + j] = lo;
+                    }
+}
+// records staged in LDS per pass
+constexpr uint32_t RCHUNK = 256u;
 // Diagnostic build only (make STAMPS=1 -> libfr_raster_stamps.so): per-phase shader-clock
 // sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
 // library is built without FR_STAMPS and executes no stamp.
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
     // s_cxp[0] = -inf, s_cxp[1 + j] = cx(j), s_cxp[1 + ncol] = +inf
     float *s_cxp = reinterpret_cast<float *>(smem);
-    uint32_t *s_rec = reinterpret_cast<uint32_t *>(smem + A.lds_region);               // [RCHUNK][RWORDS]
+    Rec *s_rec = reinterpret_cast<Rec *>(smem + A.lds_region);                          // [RCHUNK]
     unsigned char *wregion = smem + A.lds_region + A.lds_rec_bytes + (size_t)wave * A.lds_wave_bytes;
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(wregion);    // [32][nwin_pad]
     uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 
     // stage the first (usually only) 256-record chunk: one record per lane, issued first so the
     // latency hides under the cx-table divisions
-    if (tid < min(rec_cnt, RCHUNK)) rec_to_lds(s_rec + tid * RWORDS, grec[tid]);
+    if (tid < min(rec_cnt, RCHUNK)) s_rec[tid] = grec[tid];
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
@@ -204,15 +206,22 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const float wcy_top = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
     const float wcy_bot = bcast(cy, nrows ? nrows - 1u : 0u);
 
-    uint32_t e[CAP];                            // sorted ascending: (J << 16) | (sign & 0xffff)
+    // my row's crossings are APPENDED to a wave-private LDS list during the walk (one
+    // ds_write_b16 each) and sorted once afterwards; the list lives where the window masks
+    // will be (they are built after the list has been pulled into registers)
+    uint16_t *mylist = reinterpret_cast<uint16_t *>(wregion) + lane * LSTRIDE;
+    {
+        uint4 *f = reinterpret_cast<uint4 *>(mylist);
+        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) e[i] = EMPTY;
-    bool ovf = false;
+        for (uint32_t q = 0; q < CAP / 8u; ++q) f[q] = ones;       // all EMPTY
+    }
+    uint32_t cnt = 0;
 
     for (uint32_t base = 0; base < rec_cnt; base += RCHUNK) {
         if (rec_cnt > RCHUNK) {                   // multi-chunk glyph: restage (workgroup-uniform path)
             __syncthreads();
-            if (tid < RCHUNK && base + tid < rec_cnt) rec_to_lds(s_rec + tid * RWORDS, grec[base + tid]);
+            if (tid < RCHUNK && base + tid < rec_cnt) s_rec[tid] = grec[base + tid];
             __syncthreads();
         }
         const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
@@ -226,7 +235,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         bool taken = false;                     // this lane holds a latched record
         unsigned long long occ = 0;             // lanes holding one (wave-uniform)
         auto flush = [&]() {
+#if defined(FR_ABLATE) && FR_ABLATE == 5
+            if (taken && sfl == 0x12345u) {      // timing-only: no evaluation at all
+#else
             if (taken) {
+#endif
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (sfl & REC_LINEAR) != 0;
                 const float delta = cy * sa + sc1 - sc2;
@@ -252,48 +265,43 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     }
                 }
                 if (accepted && J > 0) {
-                    uint32_t x = ((uint32_t)J << 16) | ((uint32_t)sgn & 0xffffu);
-                    // sorted insert, registers only: compare-exchange chain, 8 slots at a
-                    // time; stop (wave-uniform) once every lane's carry is the EMPTY sentinel
-#pragma unroll
-                    for (int ch = 0; ch < CAP / 8; ++ch) {
-#pragma unroll
-                        for (int i = ch * 8; i < ch * 8 + 8; ++i) {
-                            const uint32_t mn = min(e[i], x);
-                            x = max(e[i], x);
-                            e[i] = mn;
-                        }
-                        if (__ballot(x != EMPTY) == 0ull) break;
-                    }
-                    if (x != EMPTY) ovf = true;
+                    if (cnt < (uint32_t)CAP) mylist[cnt] = (uint16_t)(((uint32_t)J << 1) | (sgn > 0 ? 1u : 0u));
+                    ++cnt;
                 }
             }
             taken = false;
             occ = 0;
         };
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
-            const Rec mine = rec_from_lds(s_rec + min(cb + lane, nchunk - 1u) * RWORDS);
+            // my lane's record of this 64-chunk: only its bounds are needed, for the wave-level cull
+            const uint32_t mi = min(cb + lane, nchunk - 1u);
+            const float mlo = s_rec[mi].lo, mhi = s_rec[mi].hi;
             // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
             // scalar find-first-set loop — records that miss the wave cost nothing
-            unsigned long long todo = __ballot((cb + lane < nchunk) && (mine.hi >= wcy_bot) && (mine.lo <= wcy_top));
+            unsigned long long todo = __ballot((cb + lane < nchunk) && (mhi >= wcy_bot) && (mlo <= wcy_top));
             while (todo) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float lo = bcast(mine.lo, k), hi = bcast(mine.hi, k);
-                const bool want = row_valid && cy >= lo && cy <= hi;
+                // every lane reads the SAME record: an LDS broadcast (no VALU, operands land in VGPRs)
+                const Rec rk = s_rec[cb + k];
+                const bool want = row_valid && cy >= rk.lo && cy <= rk.hi;
                 const unsigned long long wl = __ballot(want);
                 if (!wl) continue;
                 COUNT(5, 1);                    // records that touch the wave
                 COUNT(7, __popcll(wl));         // lanes they are live on
+#if defined(FR_ABLATE) && FR_ABLATE == 6
+                if (wl == 0x1234567ull) {       // timing-only: scan only, no latch, no flush
+#else
+                {
+#endif
                 if (wl & occ) { COUNT(6, 1); flush(); }
                 if (want) {
-                    sa = bcast(mine.a, k); sb = bcast(mine.b, k); sc1 = bcast(mine.c1, k);
-                    sc2 = bcast(mine.c2, k); sax = bcast(mine.ax, k); sbx = bcast(mine.bx, k);
-                    sp0x = bcast(mine.p0x, k); srd = bcast(mine.rden, k);
-                    sfl = (uint32_t)__builtin_amdgcn_readlane((int)mine.flags, (int)k);
+                    sa = rk.a; sb = rk.b; sc1 = rk.c1; sc2 = rk.c2; sax = rk.ax; sbx = rk.bx;
+                    sp0x = rk.p0x; srd = rk.rden; sfl = rk.flags;
                     taken = true;
                 }
                 occ |= wl;
+                }
             }
         }
         if (occ) { COUNT(6, 1); flush(); }
@@ -301,6 +309,56 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     COUNT(4, 1);                                // wave bands
     STAMP(1);                                   // phase 1: record walk
     if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
+    if (__ballot(cnt != 0u) == 0ull) {
+        // ---- no crossing on any of my 64 sample rows: every winding is 0 — store the band's
+        // background directly (cell padding, rows above/below the outline); no lists, no masks
+        if (lane == 0) A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = 0ull;
+        const uint32_t bg = (MODE == MODE_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0*20+100) = 100 (:28)
+        const uint32_t prows_b = nrows / N;
+        const uint32_t wx = lane & (nwin_pad - 1u);
+        const uint32_t px0 = wx * 16u;
+        if (px0 < sw) {
+            const uint32_t nvalid = min(16u, sw - px0);
+            for (uint32_t yl = lane >> nwin_log; yl < prows_b; yl += (64u >> nwin_log)) {
+                const size_t eidx = ((size_t)job.out_y + y0 + yl) * A.out_stride + out_col0 + px0;
+                if (MODE == MODE_WINDING_I16) {
+                    int16_t *dst = reinterpret_cast<int16_t *>(A.out) + eidx;
+                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(0, 0, 0, 0);
+                        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(0, 0, 0, 0);
+                    } else {
+                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = 0;
+                    }
+                } else {
+                    uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + eidx;
+                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(bg, bg, bg, bg);
+                    } else {
+                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)bg;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();                        // my prefilled list vs. the next band's prefill
+        continue;
+    }
+    // ---- pull my list into registers and sort it by J (network size = the wave's fullest row)
+    const bool ovf = cnt > (uint32_t)CAP;
+    uint32_t e[32];
+    {
+        const uint4 *f = reinterpret_cast<const uint4 *>(mylist);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = f[q];
+            e[8 * q + 0] = v.x & 0xffffu; e[8 * q + 1] = v.x >> 16; e[8 * q + 2] = v.y & 0xffffu; e[8 * q + 3] = v.y >> 16;
+            e[8 * q + 4] = v.z & 0xffffu; e[8 * q + 5] = v.z >> 16; e[8 * q + 6] = v.w & 0xffffu; e[8 * q + 7] = v.w >> 16;
+        }
+        if (CAP > 16 && __ballot(cnt > 16u) != 0ull) sort_network<32>(e);
+        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) sort_network<16>(e);
+        else sort_network<8>(e);
+    }
+    wave_lds_sync();                            // the list region becomes the mask region below
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
     // publish which of my 64 sample rows they are (one word per wave band, always written)
     {
@@ -332,15 +390,15 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 if (!ovf) {
                     int run = 0;
 #pragma unroll
-                    for (int ch = CAP / 8 - 1; ch >= 0; --ch) {
+                    for (int ch = 3; ch >= 0; --ch) {
                         if (__ballot(e[ch * 8] != EMPTY) == 0ull) continue;     // sorted: chunk empty in every lane
 #pragma unroll
                         for (int i = ch * 8 + 7; i >= ch * 8; --i) {
                             if (e[i] != EMPTY) {
                                 const int before = run;
-                                run += (int)(int16_t)(e[i] & 0xffffu);
+                                run += (e[i] & 1u) ? 1 : -1;
                                 if ((run != 0) != (before != 0)) {
-                                    const uint32_t t = e[i] >> 16;                  // 1 .. ncol
+                                    const uint32_t t = e[i] >> 1;                   // 1 .. ncol
                                     const uint32_t wv = (t - 1u) >> WSHIFT;
                                     const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
                                     atomicXor(line + wv, ~0ull >> (64u - cb));
@@ -424,8 +482,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #pragma unroll
                 for (int i = CAP - 1; i >= 0; --i) {
                     const bool have = e[i] != EMPTY;
-                    if (have) run += (int)(int16_t)(e[i] & 0xffffu);
-                    dst[i] = have ? ((e[i] & 0xffff0000u) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
+                    if (have) run += (e[i] & 1u) ? 1 : -1;
+                    dst[i] = have ? (((e[i] >> 1) << 16) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
                 }
                 if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
             }
@@ -560,8 +618,9 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     while ((1u << lg) < nwin) ++lg;
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
     const size_t prow = 64u / FR_BAND_PARTS;
-    const size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
-    const size_t rb = ((size_t)RCHUNK * RWORDS * 4 + 15) & ~(size_t)15;
+    size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
+    if (wb < 64u * LSTRIDE * 2u) wb = 64u * LSTRIDE * 2u;     // the crossing lists of the walk live here first
+    const size_t rb = (size_t)RCHUNK * sizeof(Rec);
     const size_t t = cx + rb + 4 * wb;
     *rec_bytes = (uint32_t)rb;
     *nwin_log = lg; *region = (uint32_t)cx; *wave_bytes = (uint32_t)wb; *tail = (uint32_t)t;
