@@ -224,7 +224,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             if (tid < RCHUNK && base + tid < rec_cnt) s_rec[tid] = grec[base + tid];
             __syncthreads();
         }
+#if defined(FR_ABLATE) && FR_ABLATE == 8
+        const uint32_t nchunk = (A.n_jobs == 0xffffffffu) ? 1u : 0u;   // timing-only: no walk
+#else
         const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
+#endif
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane.
         // Neighbouring segments of a contour stack vertically, so consecutive records are live
         // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
@@ -258,8 +262,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
                 int J = (int)gf;
                 {
-                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
-                    if (!(c0 <= xx && xx < c1)) {
+                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];    // one ds_read2_b32
+                    const bool good = (c0 <= xx) & (xx < c1);        // '&': both loads issue together
+                    if (!good) {
                         while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
                         while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
                     }
@@ -279,11 +284,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
             // scalar find-first-set loop — records that miss the wave cost nothing
             unsigned long long todo = __ballot((cb + lane < nchunk) && (mhi >= wcy_bot) && (mlo <= wcy_top));
+            // every lane reads the SAME record: an LDS broadcast (operands land in VGPRs); the
+            // read for the next record is issued before the current one is processed
+            Rec rnext = s_rec[cb + (todo ? (uint32_t)__builtin_ctzll(todo) : 0u)];
             while (todo) {
-                const uint32_t k = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                // every lane reads the SAME record: an LDS broadcast (no VALU, operands land in VGPRs)
-                const Rec rk = s_rec[cb + k];
+                const Rec rk = rnext;
+                if (todo) rnext = s_rec[cb + (uint32_t)__builtin_ctzll(todo)];
                 const bool want = row_valid && cy >= rk.lo && cy <= rk.hi;
                 const unsigned long long wl = __ballot(want);
                 if (!wl) continue;
@@ -384,7 +391,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             }
             wave_lds_sync();
             // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity
+#if defined(FR_ABLATE) && FR_ABLATE == 2
+            if (mine_half && A.n_jobs == 0xffffffffu) {     // timing-only: no toggles
+#else
             if (mine_half) {
+#endif
                 unsigned long long *line = s_mask + ((size_t)mask_line(hrow) << nwin_log);
                 uint32_t fill = 0;
                 if (!ovf) {
@@ -416,7 +427,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             // ---- phase 2: one lane per 16-pixel window
             const uint32_t wx = lane & (nwin_pad - 1u);
             const uint32_t px0 = wx * 16u;
+#if defined(FR_ABLATE) && FR_ABLATE == 3
+            if (px0 < sw && A.n_jobs == 0xffffffffu) {      // timing-only: no windows, no stores
+#else
             if (px0 < sw) {
+#endif
                 const uint32_t nvalid = min(16u, sw - px0);
                 for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) {
                     unsigned long long mask[N];
