@@ -16,3 +16,4 @@ from .render_glyph import (  # noqa: F401
     Context, GlyphInfo, Plan, DeviceGlyphSet, renderGlyph, render_glyph_dims, windingInGlyph,
     winding_lattice,
 )
+from .font import Font  # noqa: F401

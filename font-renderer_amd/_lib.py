@@ -60,6 +60,12 @@ SYMBOLS = [
     ("fr_glyph_info_init", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("fr_winding_in_glyph", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     ("fr_winding_lattice", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    ("fr_font_open", C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
+    ("fr_font_close", None, [_P]),
+    ("fr_font_info", C.c_int, [_P, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int)]),
+    ("fr_font_char_to_glyph", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint16)]),
+    ("fr_font_glyph_measure", C.c_int, [_P, C.c_uint16, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
+    ("fr_font_glyph_fill", C.c_int, [_P, C.c_uint16, _P, _P]),
     ("fr_selftest_division", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 

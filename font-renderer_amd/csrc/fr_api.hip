@@ -39,6 +39,16 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+namespace fr {
+int set_error(int code, const char *fmt, ...)          // for the other translation units (fr_font.cpp)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace fr
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

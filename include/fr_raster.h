@@ -165,6 +165,24 @@ int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *c
 int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                        uint32_t n_contours, const int16_t box[4], int16_t *out_host);
 
+/* ---- contour producer (host side): TrueType glyf/loca -> Glyph contour layout ------------
+ * What font/Font.zig + font/ttf.zig + font/Glyph.zig do in the reference (Font.initTTF :31,
+ * loadGlyph :171, SimpleGlyph.initFromReader ttf.zig:759, ComponentGlyph ttf.zig:830,
+ * Contour.initTTF Glyph.zig:43, initTTFComponent :108, transform1 :178), restated in C++ so
+ * whole fonts can be batch-fed to fr_glyphset_create without the Zig host.  The font bytes are
+ * copied; glyphs are parsed lazily and cached like Font.glyphs.  Where the reference
+ * @panic("not impl")s these return FR_E_UNSUPPORTED (hinted glyphs unless FR_FONT_ALLOW_HINTED).
+ * fr_font_glyph_measure gives the sizes to allocate, fr_font_glyph_fill writes the i16 (x,y)
+ * points and the n_contours+1 contour offsets (relative to the glyph, starting at 0).           */
+typedef struct fr_font fr_font;
+#define FR_FONT_ALLOW_HINTED 1u
+int fr_font_open(const void *ttf_bytes, size_t len, uint32_t flags, fr_font **out);
+void fr_font_close(fr_font *font);
+int fr_font_info(const fr_font *font, uint16_t *units_per_em, uint16_t *num_glyphs, int *y0_baseline);
+int fr_font_char_to_glyph(const fr_font *font, uint32_t codepoint, uint16_t *glyph_index);
+int fr_font_glyph_measure(fr_font *font, uint16_t glyph_index, uint32_t *n_contours, uint32_t *n_points, int16_t box[4]);
+int fr_font_glyph_fill(fr_font *font, uint16_t glyph_index, int16_t *points_xy, uint32_t *contour_start);
+
 /* ---- self-test: exhaustive device-side check of an arithmetic shortcut ----------
  * The render kernel computes t = num / d (render_glyph.zig:51,60-61; d an integer, |d| <= 2^17)
  * as a reciprocal multiply + FMA correction.  This compares that sequence with IEEE division

@@ -210,38 +210,55 @@ def test_exact_integer_path(ctx, oracle, ascii_set):
     assert np.array_equal(fr.windingInGlyph(gg, None, qq, ctx=ctx), oracle.winding_in_glyph(gg, qq))
 
 
-def test_full_size_properties_config3_shape(ctx):
-    """BASELINE configs[2] shape at reduced count (512 glyphs x 256^2, S = 128, 16 samples):
-    size-independent properties instead of the oracle — sharded == unsharded byte for byte
-    (SURVEY §4 item 5), idempotent re-render, n=1 coverage == mask, untouched background."""
+def test_full_size_properties_config3(ctx):
+    """BASELINE configs[2] at FULL size (20 992 glyphs x 256^2, S = 128, 16 samples/pixel, 1.376
+    Gpixel): too big for the oracle, so size-independent properties — re-render is idempotent,
+    8 shards rendered one after another == the unsharded atlas byte for byte (SURVEY §4 item 5:
+    the single-GPU "fake cluster"), a 64-glyph prefix equals the oracle-checked small render,
+    and the inside fraction is sane.  Everything stays on the device (torch.equal)."""
     import torch
-    gs = synth_glyphset(512, 128)
-    cols, cell = 16, 256
-    H, W = atlas_shape(512, cell, cols)
+    from font_renderer_amd.shard import shard_ranges
+    G, cols, cell = 20992, 64, 256
+    gs = synth_glyphset(G, 128)
+    H, W = atlas_shape(G, cell, cols)
     dgs = fr.DeviceGlyphSet(ctx, gs)
     jobs = cell_jobs(gs, cell, cell, 2048, cols)
     out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    assert plan.pixels == G * cell * cell
     plan.render(out.data_ptr(), W, H); ctx.sync()
-    a = out.cpu().numpy().copy()
-    plan.render(out.data_ptr(), W, H); ctx.sync()
-    assert np.array_equal(out.cpu().numpy(), a)                     # idempotent
-    assert plan.pixels == 512 * cell * cell
-    # "fake cluster": 8 shards rendered one after another into their own row bands
-    from font_renderer_amd.shard import shard_ranges
+    first = out.clone()
+    dgs.prepare(); plan.render(out.data_ptr(), W, H); ctx.sync()
+    assert torch.equal(out, first)                                   # idempotent (prepare + render)
     out2 = torch.zeros_like(out)
-    for lo, hi in shard_ranges(512, 8):
+    for lo, hi in shard_ranges(G, 8):                                # 2 624 glyphs = 41 atlas rows per shard
         sub = gs.subset(lo, hi)
         sd = fr.DeviceGlyphSet(ctx, sub)
-        sj = cell_jobs(sub, cell, cell, 2048, cols)
         band = out2[(lo // cols) * cell:]
-        sp = fr.Plan(sd, sj, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        sp = fr.Plan(sd, cell_jobs(sub, cell, cell, 2048, cols), fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
         sp.render(band.data_ptr(), W, band.shape[0]); ctx.sync()
         sp.close(); sd.close()
-    assert np.array_equal(out2.cpu().numpy(), a)
-    frac = (a > 0).mean()
+    assert torch.equal(out2, first)
+    frac = float((first[: 8 * cell] > 0).float().mean())
     assert 0.2 < frac < 0.8
-    plan.close(); dgs.close()
+    # the first atlas row (64 glyphs) against a separately rendered small batch
+    small = torch.zeros((cell, W), dtype=torch.uint8, device="cuda")
+    sub = gs.subset(0, cols)
+    sd = fr.DeviceGlyphSet(ctx, sub)
+    sp = fr.Plan(sd, cell_jobs(sub, cell, cell, 2048, cols), fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    sp.render(small.data_ptr(), W, cell); ctx.sync()
+    assert torch.equal(small, first[:cell])
+    sp.close(); sd.close(); plan.close(); dgs.close()
+
+
+def test_oracle_spot_check_inside_full_size_workload(ctx, oracle):
+    """4 cells of the C3 workload (first, two middle, last glyph index) against the oracle."""
+    G = 20992
+    for gi in (0, 7777, 15000, G - 1):
+        gs = synth_glyphset(1, 128, first_index=gi)
+        jobs = cell_jobs(gs, 256, 256, 2048, 1)
+        got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, (256, 256), 4, True, threads=16)
+        assert np.array_equal(got, ref), gi
 
 
 def test_cpp_host_mirror(ctx, ascii_set, tmp_path):
@@ -277,3 +294,32 @@ def test_division_shortcut_is_exact_exhaustively(ctx):
     m, bd, bx = C.c_uint64(1), C.c_uint32(), C.c_uint32()
     _lib.check(lib.fr_selftest_division(1, 1 << 17, C.byref(m), C.byref(bd), C.byref(bx)))
     assert m.value == 0, f"{m.value} mismatches, e.g. divisor {bd.value}, x bits {bx.value:#x}"
+
+
+def test_whole_font_from_the_c_side_producer(ctx, oracle):
+    """SURVEY §8f-1 end to end: TrueType bytes -> fr_font_* (C++ contour producer) -> glyph set ->
+    one atlas of every glyph the reference could load (DejaVuSerif-Italic: ~3 000 glyphs incl.
+    composites), 16 samples/pixel; 48 random cells against the oracle."""
+    import os
+    path = "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"
+    if not os.path.exists(path):
+        pytest.skip("font not present")
+    font = fr.Font.initTTF(path)
+    gs, kept = font.glyphset()
+    assert len(kept) > 3000
+    cell, cols = 48, 64
+    jobs = cell_jobs(gs, cell, 40, font.information.units_per_em, cols)
+    H, W = atlas_shape(len(gs), cell, cols)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    atlas = np.zeros((H, W), np.uint8)
+    rg.render_batch(dgs, jobs, fr.FR_COVERAGE_U8, atlas, 4, fr.FR_SAMPLE_CENTER)
+    dgs.close()
+    rng = np.random.default_rng(9)
+    for k in rng.choice(len(gs), 48, replace=False):
+        sub = gs.subset(int(k), int(k) + 1)
+        j1 = cell_jobs(sub, cell, 40, font.information.units_per_em, 1)
+        ref = np.zeros((cell, cell), np.uint8)
+        oracle.render_batch(sub, j1, O.COVERAGE_U8, ref, 4, True)
+        y, x = (int(k) // cols) * cell, (int(k) % cols) * cell
+        assert np.array_equal(atlas[y:y + cell, x:x + cell], ref), int(k)
+    assert (atlas > 0).mean() > 0.02
