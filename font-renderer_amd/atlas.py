@@ -35,3 +35,10 @@ def cell_jobs(gs: GlyphSet, cell: int, font_size: int, units_per_em, cols: int, 
 def atlas_shape(n_glyphs: int, cell: int, cols: int):
     rows = (n_glyphs + cols - 1) // cols
     return rows * cell, cols * cell
+
+
+def atlas_pages(n_glyphs: int, cell: int, page: int = 2048):
+    """cell grid on page x page atlas pages (BASELINE configs[1]: 128-cells on one 2048^2 page):
+    -> list of (first_glyph, n_glyphs_on_page); cols = page // cell for every page"""
+    per = (page // cell) ** 2
+    return [(s, min(per, n_glyphs - s)) for s in range(0, n_glyphs, per)]

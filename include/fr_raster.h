@@ -183,6 +183,14 @@ int fr_font_char_to_glyph(const fr_font *font, uint32_t codepoint, uint16_t *gly
 int fr_font_glyph_measure(fr_font *font, uint16_t glyph_index, uint32_t *n_contours, uint32_t *n_points, int16_t box[4]);
 int fr_font_glyph_fill(fr_font *font, uint16_t glyph_index, int16_t *points_xy, uint32_t *contour_start);
 
+/* ---- QOI writer (host side), byte-compatible with tools/qoi.zig:25-88 saveRGB -----------
+ * RGB-only stream, op order RUN -> INDEX -> DIFF -> LUMA -> RGB, run cap 62, BE header, 8-byte
+ * trailer.  fr_qoi_encode_gray feeds an Image.Gray (or an atlas page) through getRGBLinear =
+ * {v,v,v} (Image.zig:78-82).  *n_out receives the stream length; FR_E_INVALID if cap is short. */
+size_t fr_qoi_bound(uint32_t width, uint32_t height);
+int fr_qoi_encode_rgb(const uint8_t *rgb, uint32_t width, uint32_t height, uint8_t *out, size_t cap, size_t *n_out);
+int fr_qoi_encode_gray(const uint8_t *gray, uint32_t width, uint32_t height, size_t stride, uint8_t *out, size_t cap, size_t *n_out);
+
 /* ---- self-test: exhaustive device-side check of an arithmetic shortcut ----------
  * The render kernel computes t = num / d (render_glyph.zig:51,60-61; d an integer, |d| <= 2^17)
  * as a reciprocal multiply + FMA correction.  This compares that sequence with IEEE division
