@@ -9,7 +9,7 @@ the shared library and raises if it (or a GPU) is missing.
 from .glyph import Box, Contour, FontInformation, Glyph, GlyphSet  # noqa: F401
 from .image import Gray, Winding  # noqa: F401
 from ._lib import (  # noqa: F401
-    FR_COVERAGE_U8, FR_GRAY_DEBUG, FR_MASK_NONZERO, FR_SAMPLE_CENTER, FR_SAMPLE_CORNER,
+    FR_COVERAGE_U8, FR_SDF_U8, FR_GRAY_DEBUG, FR_MASK_NONZERO, FR_SAMPLE_CENTER, FR_SAMPLE_CORNER,
     FR_WINDING_I16, FrError, Job, lib_path, load_library,
 )
 from .render_glyph import (  # noqa: F401

@@ -6,7 +6,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FR_WINDING_I16, FR_GRAY_DEBUG, FR_MASK_NONZERO, FR_COVERAGE_U8 = 0, 1, 2, 3
+FR_WINDING_I16, FR_GRAY_DEBUG, FR_MASK_NONZERO, FR_COVERAGE_U8, FR_SDF_U8 = 0, 1, 2, 3, 4
 FR_SAMPLE_CORNER, FR_SAMPLE_CENTER = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

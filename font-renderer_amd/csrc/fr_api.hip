@@ -18,6 +18,7 @@ namespace fr {
 void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *, uint32_t *,
                     hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
+hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
                        uint8_t *, hipStream_t);
 void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
@@ -84,7 +85,7 @@ struct fr_plan {
     uint32_t *d_ovf_count = nullptr;
     uint32_t n_jobs = 0;
     fr_raster_params params{};
-    uint32_t bands = 0, strips = 0, strip_w = 0;
+    uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
     uint64_t pixels = 0, need_cols = 0, need_rows = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -286,7 +287,7 @@ int fr_glyphset_stats(const fr_glyphset *gs, uint64_t *n_segments, uint64_t *n_r
 static int check_params(const fr_raster_params *p)
 {
     if (!p) return fail(FR_E_INVALID, "params is NULL");
-    if (p->mode < FR_WINDING_I16 || p->mode > FR_COVERAGE_U8) return fail(FR_E_INVALID, "unknown mode %d", p->mode);
+    if (p->mode < FR_WINDING_I16 || p->mode > FR_SDF_U8) return fail(FR_E_INVALID, "unknown mode %d", p->mode);
     const int n = p->samples_per_axis;
     if (p->mode == FR_COVERAGE_U8) {
         if (n != 1 && n != 2 && n != 4) return fail(FR_E_UNSUPPORTED, "samples_per_axis %d not in {1,2,4}", n);
@@ -340,6 +341,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (!p) return fail(FR_E_NOMEM, "fr_plan_create: host allocation");
     p->ctx = ctx; p->gs = gs; p->n_jobs = n_jobs; p->params = *params;
     p->pixels = pixels; p->need_cols = need_cols; p->need_rows = need_rows;
+    p->max_w = max_w; p->max_h = max_h;
     const uint32_t band = 64u / n;                                      // pixel rows per wave band
     const uint32_t cap_w = ctx->strip_px;                               // strip width cap, pixels
     uint32_t sw = (max_w + 15u) & ~15u;
@@ -401,6 +403,10 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.ovf_bits = plan->d_ovf_bits;
     a.ovf_count = plan->d_ovf_count;
     HIP_TRY(hipSetDevice(plan->ctx->device));
+    if (plan->params.mode == FR_SDF_U8) {
+        HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
+        return FR_OK;
+    }
     HIP_TRY(hipMemsetAsync(plan->d_ovf_count, 0, 4, plan->ctx->stream));
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;

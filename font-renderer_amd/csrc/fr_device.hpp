@@ -129,6 +129,21 @@ __device__ __forceinline__ bool rec_cross(const Rec &r, float cy, float &xx, int
     return ok;
 }
 
+// direct sum over a glyph's records — the reference's own loop shape (render_glyph.zig:37-71):
+// used for over-full rows (fixup_kernel) and for the sign of the SDF
+__device__ inline int brute_winding(const Rec *__restrict__ recs, uint32_t n, float cx, float cy)
+{
+    int w = 0;
+    for (uint32_t c = 0; c < n; ++c) {
+        const Rec r = recs[c];
+        if (cy >= r.lo && cy <= r.hi) {
+            float xx; int sgn;
+            if (rec_cross(r, cy, xx, sgn) && !(xx < cx)) w += sgn;
+        }
+    }
+    return w;
+}
+
 // sub-sample offset (k + phase)/n — exact in binary32 for n in {1,2,4}
 __device__ __forceinline__ float sub_off(int k, int n, int phase_center)
 {

@@ -34,20 +34,6 @@ namespace fr {
 
 enum { MODE_WINDING_I16 = 0, MODE_GRAY_DEBUG = 1, MODE_MASK_NONZERO = 2, MODE_COVERAGE_U8 = 3 };
 
-// direct sum over the glyph's records — the fallback for over-full rows
-__device__ __noinline__ int brute_winding(const Rec *__restrict__ recs, uint32_t n, float cx, float cy)
-{
-    int w = 0;
-    for (uint32_t c = 0; c < n; ++c) {
-        const Rec r = recs[c];
-        if (cy >= r.lo && cy <= r.hi) {
-            float xx; int sgn;
-            if (rec_cross(r, cy, xx, sgn) && !(xx < cx)) w += sgn;
-        }
-    }
-    return w;
-}
-
 __device__ __forceinline__ uint32_t gray_debug(int w)
 {
     int v = w * 20 + 100;                       // render_glyph.zig:28

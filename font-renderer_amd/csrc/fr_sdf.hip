@@ -1,0 +1,116 @@
+// fr_sdf.hip — per-pixel signed distance field (BASELINE configs[4]).  BUILD-DEFINED: the
+// reference has no SDF; the definition below is this library's.  The test checker
+// keeps a CPU twin written from this definition (same operations in the same order, no FMA
+// contraction, IEEE divide/sqrt), so the two agree bit for bit.
+//
+//   sample     : the pixel's sample point exactly as renderGlyph's (render_glyph.zig:26-27),
+//                n = 1, phase corner or centre
+//   distance   : min over the glyph's quadratic segments B(t) = p0 + 2t(p1-p0) + t^2(p0-2p1+p2),
+//                t in [0,1], of |B(t) - q| (font units): 9 uniform probes, then 4 Newton steps on
+//                (B(t)-q).B'(t) = 0 clamped to the probe's neighbourhood; times `scale` -> pixels
+//   sign       : + inside (winding != 0, the reference's non-zero test on its own winding number,
+//                render_glyph.zig:29,35-73), - outside
+//   encoding   : u8 = clamp(floor(128 + 16*d + 0.5), 0, 255)   (8 pixels of range either side)
+//
+// Shape: one workgroup per 16x16-pixel tile of a cell, one lane per pixel; the glyph's control
+// points are staged through LDS as f32 (256 segments at a time) and read back as broadcasts.
+// Brute force, O(segments) per pixel: VALU-bound by design, not a bandwidth kernel.
+#include "fr_device.hpp"
+
+namespace fr {
+
+__device__ __forceinline__ float seg_dist2(float p0x, float p0y, float p1x, float p1y, float p2x, float p2y,
+                                           float qx, float qy)
+{
+    const float ax = p1x - p0x, ay = p1y - p0y;                         // A
+    const float bx = p0x - 2.0f * p1x + p2x, by = p0y - 2.0f * p1y + p2y;   // second difference
+    float best = 3.402823466e+38f, bt = 0.0f;
+    for (int k = 0; k <= 8; ++k) {
+        const float t = (float)k * 0.125f;
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float d2 = x * x + y * y;
+        if (d2 < best) { best = d2; bt = t; }
+    }
+    const float lo = fmaxf(bt - 0.125f, 0.0f), hi = fminf(bt + 0.125f, 1.0f);
+    float t = bt;
+    for (int it = 0; it < 4; ++it) {
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float dx = 2.0f * (ax + t * bx), dy = 2.0f * (ay + t * by);
+        const float f = x * dx + y * dy;
+        const float fp = dx * dx + dy * dy + 2.0f * (x * bx + y * by);
+        if (fp > 0.0f) t = t - f / fp;
+        t = fminf(fmaxf(t, lo), hi);
+    }
+    {
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float d2 = x * x + y * y;
+        if (d2 < best) best = d2;
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, const int16_t *__restrict__ pts,
+                                                  const uint32_t *__restrict__ seg_p0,
+                                                  const uint32_t *__restrict__ glyph_seg_start,
+                                                  const uint32_t *__restrict__ glyph_rec_count,
+                                                  const Rec *__restrict__ recs, uint8_t *__restrict__ out,
+                                                  uint64_t out_stride, uint32_t tiles_x, uint32_t tiles_y,
+                                                  int phase_center)
+{
+    __shared__ float s_seg[256][6];
+    uint32_t bid = blockIdx.x;
+    const uint32_t tx = bid % tiles_x; bid /= tiles_x;
+    const uint32_t ty = bid % tiles_y;
+    const uint32_t jidx = bid / tiles_y;
+    const Job job = jobs[jidx];
+    if (tx * 16u >= job.w || ty * 16u >= job.h) return;
+    const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
+    const bool valid = x < job.w && y < job.h;
+    const float off = phase_center ? 0.5f : 0.0f;
+    const float qx = ((float)(job.min_x + (int32_t)x) + off) / job.scale;       // render_glyph.zig:26
+    const float qy = ((float)(job.max_y - (int32_t)y) - off) / job.scale;       // :27
+    const uint32_t s0 = glyph_seg_start[job.glyph], s1 = glyph_seg_start[job.glyph + 1];
+    float best = 3.402823466e+38f;
+    for (uint32_t base = s0; base < s1; base += 256u) {
+        const uint32_t s = base + threadIdx.x;
+        if (s < s1) {
+            const int16_t *p = pts + 2u * (size_t)seg_p0[s];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_seg[threadIdx.x][k] = (float)p[k];
+        }
+        __syncthreads();
+        const uint32_t n = min(256u, s1 - base);
+        if (valid)
+            for (uint32_t k = 0; k < n; ++k) {
+                const float d2 = seg_dist2(s_seg[k][0], s_seg[k][1], s_seg[k][2], s_seg[k][3], s_seg[k][4], s_seg[k][5], qx, qy);
+                if (d2 < best) best = d2;
+            }
+        __syncthreads();
+    }
+    if (!valid) return;
+    const int w = brute_winding(recs + 2u * (size_t)s0, glyph_rec_count[job.glyph], qx, qy);
+    float d = (s1 > s0) ? __builtin_sqrtf(best) * job.scale : 3.402823466e+38f;
+    if (w == 0) d = -d;
+    float v = 16.0f * d + 128.0f;
+    v = floorf(v + 0.5f);
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    out[((size_t)job.out_y + y) * out_stride + job.out_x + x] = (uint8_t)v;
+}
+
+hipError_t launch_sdf(const RenderArgs &a, const int16_t *pts, const uint32_t *seg_p0, uint32_t max_w,
+                      uint32_t max_h, hipStream_t stream)
+{
+    if (a.n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
+    const uint32_t tiles_x = (max_w + 15u) / 16u, tiles_y = (max_h + 15u) / 16u;
+    const size_t grid = (size_t)a.n_jobs * tiles_x * tiles_y;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sdf_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a.jobs, pts, seg_p0,
+                       a.glyph_seg_start, a.glyph_rec_count, a.recs, reinterpret_cast<uint8_t *>(a.out),
+                       a.out_stride, tiles_x, tiles_y, a.phase_center);
+    return hipGetLastError();
+}
+
+}  // namespace fr

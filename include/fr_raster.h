@@ -51,7 +51,11 @@ typedef enum fr_mode {
     FR_WINDING_I16 = 0,
     FR_GRAY_DEBUG = 1,
     FR_MASK_NONZERO = 2,
-    FR_COVERAGE_U8 = 3
+    FR_COVERAGE_U8 = 3,
+    FR_SDF_U8 = 4           /* BUILD-DEFINED (the reference has no SDF): u8 = clamp(round(128 + 16*d)),
+                               d = distance in pixels from the sample to the nearest quadratic segment,
+                               + inside (winding != 0) / - outside; n must be 1.  Exact definition:
+                               font-renderer_amd/csrc/fr_sdf.hip                                         */
 } fr_mode;
 
 /* Sub-sample k of an axis sits at (k + phase)/n of a pixel:

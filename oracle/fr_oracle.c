@@ -218,6 +218,8 @@ void or_render_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t n_cont
 /* ------------------------------------------------------------------------- */
 /* generic cell renderer (build-defined products on the reference's sample formula) */
 /* ------------------------------------------------------------------------- */
+static uint8_t sdf_value(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, float qx, float qy, float scale);
+
 static float sub_offset(int k, int n, int phase_center)
 {
     /* (k + phase)/n, exact in binary32 for n in {1,2,4,8,16} */
@@ -229,8 +231,18 @@ int or_render_cell(const int16_t *pts, const uint32_t *cstart, uint32_t n_contou
                    int mode, int n, int phase_center, void *out, size_t out_stride)
 {
     if (n != 1 && n != 2 && n != 4 && n != 8 && n != 16) return -1;
-    if (mode == OR_WINDING_I16 && n != 1) return -1;
-    if (mode < 0 || mode > OR_COVERAGE_U8) return -1;
+    if ((mode == OR_WINDING_I16 || mode == OR_SDF_U8) && n != 1) return -1;
+    if (mode < 0 || mode > OR_SDF_U8) return -1;
+    if (mode == OR_SDF_U8) {
+        for (uint32_t y = 0; y < h; ++y)
+            for (uint32_t x = 0; x < w; ++x) {
+                const float off = phase_center ? 0.5f : 0.0f;
+                const float qx = ((float)(min_x + (int32_t)x) + off) / scale;
+                const float qy = ((float)(max_y - (int32_t)y) - off) / scale;
+                ((uint8_t *)out)[(size_t)y * out_stride + x] = sdf_value(pts, cstart, n_contours, qx, qy, scale);
+            }
+        return 0;
+    }
     const int nn = n * n;
     for (uint32_t y = 0; y < h; ++y) {
         for (uint32_t x = 0; x < w; ++x) {
@@ -257,6 +269,66 @@ int or_render_cell(const int16_t *pts, const uint32_t *cstart, uint32_t n_contou
         }
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* BUILD-DEFINED signed distance field (no reference semantics: SURVEY F5).    */
+/* CPU twin of font-renderer_amd/csrc/fr_sdf.hip — same operations, same order */
+/* (written from the definition in that file's header comment, not shared).    */
+/* ------------------------------------------------------------------------- */
+static float sdf_seg_dist2(float p0x, float p0y, float p1x, float p1y, float p2x, float p2y, float qx, float qy)
+{
+    const float ax = p1x - p0x, ay = p1y - p0y;
+    const float bx = p0x - 2.0f * p1x + p2x, by = p0y - 2.0f * p1y + p2y;
+    float best = 3.402823466e+38f, bt = 0.0f;
+    for (int k = 0; k <= 8; ++k) {                      /* 9 uniform probes */
+        const float t = (float)k * 0.125f;
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float d2 = x * x + y * y;
+        if (d2 < best) { best = d2; bt = t; }
+    }
+    const float lo = fmaxf(bt - 0.125f, 0.0f), hi = fminf(bt + 0.125f, 1.0f);
+    float t = bt;
+    for (int it = 0; it < 4; ++it) {                    /* 4 clamped Newton steps on (B-q).B' = 0 */
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float dx = 2.0f * (ax + t * bx), dy = 2.0f * (ay + t * by);
+        const float f = x * dx + y * dy;
+        const float fp = dx * dx + dy * dy + 2.0f * (x * bx + y * by);
+        if (fp > 0.0f) t = t - f / fp;
+        t = fminf(fmaxf(t, lo), hi);
+    }
+    {
+        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
+        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+        const float d2 = x * x + y * y;
+        if (d2 < best) best = d2;
+    }
+    return best;
+}
+
+static uint8_t sdf_value(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, float qx, float qy, float scale)
+{
+    float best = 3.402823466e+38f;
+    int any = 0;
+    for (uint32_t c = 0; c < n_contours; ++c) {
+        const int16_t *cp = pts + 2 * (size_t)cstart[c];
+        uint32_t curves = (cstart[c + 1] - cstart[c]) / 2;
+        for (uint32_t k = 0; k < curves; ++k) {
+            const int16_t *p = cp + 2 * (2 * k);
+            float d2 = sdf_seg_dist2((float)p[0], (float)p[1], (float)p[2], (float)p[3], (float)p[4], (float)p[5], qx, qy);
+            if (d2 < best) best = d2;
+            any = 1;
+        }
+    }
+    const int16_t w = or_glyph_winding_at(pts, cstart, n_contours, qx, qy);   /* sign: the reference's winding */
+    float d = any ? sqrtf(best) * scale : 3.402823466e+38f;
+    if (w == 0) d = -d;
+    float v = 16.0f * d + 128.0f;
+    v = floorf(v + 0.5f);
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    return (uint8_t)v;
 }
 
 typedef struct {

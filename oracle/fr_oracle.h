@@ -72,8 +72,10 @@ void or_render_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t n_cont
  *   2 MASK_NONZERO : u8 (w != 0) ? 255 : 0                   (render_glyph.zig:29)
  *   3 COVERAGE_U8  : u8 round_half_up(255*k/(n*n)), k = #samples with w != 0
  *                    (non-zero rule :29, box filter = VulkanContext.zig:312 average resolve)
+ *   4 SDF_U8       : BUILD-DEFINED signed distance field, twin of csrc/fr_sdf.hip (n must be 1):
+ *                    u8 = clamp(floor(128 + 16*d + 0.5)), d in pixels, + where w != 0
  * out_stride in elements. */
-enum { OR_WINDING_I16 = 0, OR_GRAY_DEBUG = 1, OR_MASK_NONZERO = 2, OR_COVERAGE_U8 = 3 };
+enum { OR_WINDING_I16 = 0, OR_GRAY_DEBUG = 1, OR_MASK_NONZERO = 2, OR_COVERAGE_U8 = 3, OR_SDF_U8 = 4 };
 int or_render_cell(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
                    int32_t min_x, int32_t max_y, uint32_t w, uint32_t h, float scale,
                    int mode, int n, int phase_center, void *out, size_t out_stride);

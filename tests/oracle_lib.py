@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ODIR, "_build", "libfr_oracle.so")
 
-WINDING_I16, GRAY_DEBUG, MASK_NONZERO, COVERAGE_U8 = 0, 1, 2, 3
+WINDING_I16, GRAY_DEBUG, MASK_NONZERO, COVERAGE_U8, SDF_U8 = 0, 1, 2, 3, 4
 
 
 def build():

@@ -323,3 +323,23 @@ def test_whole_font_from_the_c_side_producer(ctx, oracle):
         y, x = (int(k) // cols) * cell, (int(k) % cols) * cell
         assert np.array_equal(atlas[y:y + cell, x:x + cell], ref), int(k)
     assert (atlas > 0).mean() > 0.02
+
+
+@pytest.mark.parametrize("center", [False, True])
+def test_sdf_matches_its_cpu_twin(ctx, oracle, ascii_set, center):
+    """FR_SDF_U8 (BASELINE configs[4]; build-defined, the reference has no SDF): GPU == the C twin in
+    the oracle bit for bit — real glyphs at 64x64 and synthetic S=64 glyphs at 96x96 (config 5 shape
+    at reduced cell size: the CPU twin is O(pixels x segments))."""
+    gs = ascii_set.gs
+    jobs = cell_jobs(gs, 64, 48, ascii_set.g_upm, 8, first_glyph=33, n_glyphs=24)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_SDF_U8, (3 * 64, 8 * 64), 1, center, threads=16)
+    assert np.array_equal(got, ref)
+    assert got.min() == 0 and got.max() > 140
+    sg = synth_glyphset(6, 64, first_index=5000)
+    sj = cell_jobs(sg, 96, 96, 2048, 3)
+    got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_SDF_U8, atlas_shape(6, 96, 3), 1, center, threads=16)
+    assert np.array_equal(got, ref)
+    # sign agrees with the coverage mask: inside -> >= 128, outside -> <= 128 (|d| < 1/32 px rounds to 128)
+    mask = np.zeros_like(got)
+    rg.render_batch(fr.DeviceGlyphSet(ctx, sg), sj, fr.FR_MASK_NONZERO, mask, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+    assert (got[mask == 255] >= 128).all() and (got[mask == 0] <= 128).all()
