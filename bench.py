@@ -94,8 +94,8 @@ def main():
     stats = dgs.stats()
 
     def step():
-        if not args.no_prep_in_step:
-            dgs.prepare()
+        # one render = everything from the glyph points to the atlas (the root records are rebuilt
+        # inside the render kernel, or by the precompute kernel the library launches with it)
         plan.render(out.data_ptr(), W, H)
 
     def barrier():
@@ -179,7 +179,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "glyphs_per_gpu": G, "cell": f"{cell}x{cell}", "segments_per_glyph": S,
                        "samples_per_pixel": n * n, "pixels_per_step_per_gpu": pixels,
-                       "root_records": stats["records"], "step": "prepare+render" if not args.no_prep_in_step else "render",
+                       "root_records": stats["records"], "step": "points -> atlas (records rebuilt every render)",
                        "parallelism": f"glyph-sharded x{world}, no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
             "gpixel_per_s": round(value / 1e3, 2), "input_gen_s": round(t_gen, 2),

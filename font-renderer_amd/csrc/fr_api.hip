@@ -64,13 +64,14 @@ struct fr_ctx {
     bool owns_stream = false;
     uint32_t kmax = 32;          // crossings kept per sample row (register array: 8, 16 or 32) before the direct-sum fallback
     uint32_t strip_px = 256;     // column strip width, pixels (multiple of 16, <= 256)
+    uint32_t fuse_prepare = 1;   // build root records inside the render kernel when every glyph has <= 128 segments
     uint32_t lds_pad = 0;        // experiment knob: extra dynamic LDS bytes per workgroup (occupancy studies)
     uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
 };
 
 struct fr_glyphset {
     fr_ctx *ctx = nullptr;
-    uint32_t n_glyphs = 0, n_contours = 0, n_seg = 0;
+    uint32_t n_glyphs = 0, n_contours = 0, n_seg = 0, max_seg_per_glyph = 0;
     uint64_t n_points = 0;
     int16_t *d_pts = nullptr;
     uint32_t *d_seg_p0 = nullptr, *d_seg_prev = nullptr, *d_glyph_seg_start = nullptr, *d_rec_count = nullptr;
@@ -151,6 +152,7 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
         ctx->strip_px = (uint32_t)value;
         return FR_OK;
     }
+    if (!strcmp(key, "fuse_prepare")) { ctx->fuse_prepare = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
     if (!strcmp(key, "min_wgs")) {
         if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
@@ -229,11 +231,13 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
             return fail(FR_E_INVALID, "glyph_start not monotone at %u", g);
         gseg[g + 1] = cseg[glyph_start[g + 1]];
     }
+    uint32_t max_seg = 0;
+    for (uint32_t g = 0; g < n_glyphs; ++g) max_seg = std::max(max_seg, gseg[g + 1] - gseg[g]);
     HIP_TRY(hipSetDevice(ctx->device));
     fr_glyphset *gs = new (std::nothrow) fr_glyphset;
     if (!gs) return fail(FR_E_NOMEM, "fr_glyphset_create: host allocation");
     gs->ctx = ctx; gs->n_glyphs = n_glyphs; gs->n_contours = n_contours;
-    gs->n_seg = (uint32_t)seg_p0.size(); gs->n_points = np;
+    gs->n_seg = (uint32_t)seg_p0.size(); gs->n_points = np; gs->max_seg_per_glyph = max_seg;
     const size_t nseg1 = gs->n_seg ? gs->n_seg : 1, np1 = np ? np : 1;
 #define GS_TRY(expr)                                                                          \
     do {                                                                                      \
@@ -386,6 +390,10 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.glyph_seg_start = plan->gs->d_glyph_seg_start;
     a.glyph_rec_count = plan->gs->d_rec_count;
     a.recs = plan->gs->d_recs;
+    a.pts = plan->gs->d_pts;
+    a.seg_p0 = plan->gs->d_seg_p0;
+    // fused: the render kernel builds each glyph's records in LDS itself (<= 256 candidate roots)
+    a.fused = (plan->ctx->fuse_prepare && plan->gs->max_seg_per_glyph <= 128u) ? 1u : 0u;
     a.out = out_dev;
     a.out_stride = out_stride;
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
@@ -408,6 +416,11 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         return FR_OK;
     }
     HIP_TRY(hipMemsetAsync(plan->d_ovf_count, 0, 4, plan->ctx->stream));
+    // a render always starts from the glyph POINTS: either inside the render kernel (fused) or by
+    // re-running the stand-alone precompute first
+    if (!a.fused)
+        fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->gs->n_glyphs,
+                           plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;
 }

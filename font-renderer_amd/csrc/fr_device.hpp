@@ -67,6 +67,9 @@ struct RenderArgs {
     const uint32_t *glyph_seg_start;   // record slice of glyph g starts at 2*glyph_seg_start[g]
     const uint32_t *glyph_rec_count;
     const Rec *recs;
+    const int16_t *pts;                // glyph points / per-segment p0 index: the render kernel builds its
+    const uint32_t *seg_p0;            // glyph's records itself (in LDS) when `fused` is set
+    uint32_t fused;
     void *out;
     unsigned long long *ovf_bits;      // [n_jobs][bands][strips]: over-full sample rows of each wave band
     uint32_t *ovf_count;               // number of wave bands with any (zeroed before each render)

@@ -1,110 +1,9 @@
-// fr_prepare.hip — per-segment precompute: root records with GUARANTEED acceptance brackets.
-//
-// Why a bracket is sound.  For one root of one segment the reference decides "accept" from
-// (render_glyph.zig:58-64)
-//        delta = fl(fl(fl(cy*a) + c1) - c2);   reject if delta < 0
-//        t     = fl(fl(B +/- sqrt(delta)) / a); reject if t < 0 or t >= 1
-// with a, B, c1, c2 constants of the segment.  Every step is a correctly rounded IEEE
-// operation with one varying operand, hence a monotone function of it; so delta(cy) is
-// monotone (direction = sign a), sqrt is non-decreasing, and t+(cy) is non-decreasing /
-// t-(cy) non-increasing for either sign of a.  The three rejection tests are therefore each a
-// one-sided cut of the cy axis: classify() below is a monotone step function 0 -> 1 -> 2
-// ("below the accepted set", "accepted", "above it") over the ordered binary32 values.
-// Consequently ONE probe with class 0 proves that every smaller cy is rejected, and one probe
-// with class 2 proves the same for every larger cy.  We probe the three heights where the
-// cuts sit in exact arithmetic (t = 0 at p0y, t = 1 at p2y, delta = 0 at the vertex) and a few
-// rounding-plateau widths either side of them, evaluating the reference's own expression, and
-// keep  lo = just above the highest class-0 probe,  hi = just below the lowest class-2 probe.
-// [lo, hi] CONTAINS the accepted set (exactly, not approximately); the render kernel culls
-// with it and still applies the reference's own three tests to whatever survives, so the
-// bracket only ever saves work.  The same holds for the a == 0 branch (:51-52).
-#include "fr_device.hpp"
+// fr_prepare.hip — stand-alone per-glyph-set precompute of the root records (fr_records.hpp).
+// Used at glyph-set creation (the records serve fixup_kernel and the SDF sign) and, per render,
+// for glyphs too large for the render kernel's in-LDS record build.
+#include "fr_records.hpp"
 
 namespace fr {
-
-// 0 = cy lies below the accepted interval, 1 = accepted, 2 = above
-__device__ __forceinline__ int classify(const Rec &r, float cy)
-{
-    if (r.flags & REC_LINEAR) {
-        float t = rec_t_lin(r, cy);
-        bool up = r.c1 > 0.0f;                         // den > 0: t non-decreasing in cy
-        if (t < 0.0f) return up ? 0 : 2;               // :52
-        if (t >= 1.0f) return up ? 2 : 0;
-        return 1;
-    }
-    float delta = cy * r.a + r.c1 - r.c2;              // :58
-    if (delta < 0.0f) return (r.a > 0.0f) ? 0 : 2;     // :59
-    float t = rec_t_quad(r, cy);
-    bool neg = (r.flags & REC_NEG_ROOT) != 0;          // t- is non-increasing in cy
-    if (t < 0.0f) return neg ? 2 : 0;                  // :64
-    if (t >= 1.0f) return neg ? 0 : 2;
-    return 1;
-}
-
-// Smallest key k in [L, H] such that class(k) >= T, given the invariant
-//   every key <  L has class <  T,   every key >= H has class >= T      (class is monotone).
-// Only used when the cheap probes leave a side unbounded (rare): exponential, then bisection.
-__device__ __noinline__ uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint32_t H)
-{
-    uint32_t step = 1u;
-    while (step < (1u << 30) && H - L > 2u * step) {
-        const uint32_t pl = L + step - 1u;
-        if (classify(r, key2f(pl)) >= T) { H = pl; break; }
-        L = pl + 1u;
-        const uint32_t ph = H - step;
-        if (classify(r, key2f(ph)) < T) { L = ph + 1u; break; }
-        H = ph;
-        step <<= 1;
-    }
-    while (L < H) {
-        const uint32_t mid = L + ((H - L) >> 1);
-        if (classify(r, key2f(mid)) >= T) H = mid; else L = mid + 1u;
-    }
-    return L;
-}
-
-__device__ inline bool accept_bracket(const Rec &r, float p0y, float p2y, float &lo, float &hi)
-{
-    const uint32_t kmin = f2key(-3.402823466e+38f), kmax = f2key(3.402823466e+38f);
-    // LB: every key < LB is class 0.  HB: every key >= HB is class 2.
-    uint32_t LB = kmin, HB = kmax + 1u;
-    bool seen1 = false;
-    auto probe = [&](float c) {
-        if (!(c >= -3.402823466e+38f && c <= 3.402823466e+38f)) return;      // hints only
-        const uint32_t k = f2key(c);
-        const int cl = classify(r, c);
-        if (cl == 0) { if (k + 1u > LB) LB = k + 1u; }
-        else if (cl == 2) { if (k < HB) HB = k; }
-        else seen1 = true;
-    };
-    // width of one rounding plateau of cy*a + c1 near the glyph: ulp(max|c1|,|c2|) / |a|
-    float w = 0.0f;
-    float cand[3];
-    int ncand = 2;
-    cand[0] = p0y; cand[1] = p2y;
-    if (!(r.flags & REC_LINEAR)) {
-        cand[2] = p0y - (r.b * r.b) / r.a;                                    // vertex: y(B/a)
-        ncand = 3;
-        const float big = fmaxf(fmaxf(fabsf(r.c1), fabsf(r.c2)), 1.0f);
-        w = (big * 1.1920929e-07f) / fabsf(r.a);                              // ~ulp(big)/|a|
-    }
-    for (int i = 0; i < ncand; ++i) {
-        const float c = cand[i];
-        const float d = fmaxf(4.0f * w, fabsf(c) * 4.76837158e-07f);          // >= 4 plateaus, >= 4 ulp
-        probe(c - d);
-        probe(c);
-        probe(c + d);
-    }
-    if (LB >= HB) return false;                          // class 0 up to LB-1, class 2 from HB: never accepted
-    // a side the probes did not bound (no class-0 / class-2 probe at all): settle it exactly
-    if (LB == kmin) LB = first_at_least(r, 1, kmin, HB);
-    if (HB == kmax + 1u) HB = first_at_least(r, 2, LB, kmax + 1u);
-    if (LB >= HB) return false;
-    (void)seen1;
-    lo = key2f(LB);
-    hi = key2f(HB - 1u);
-    return true;
-}
 
 // One wave64 per glyph.  Lane l builds candidate record c = base + l, where
 // candidate 2s / 2s+1 are the t+ / t- roots of segment s (2s alone for a == 0);
@@ -128,39 +27,10 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
         const uint32_t c = base + lane;
         bool valid = false;
         Rec r;
-        r.rden = 0.0f; r.pad1 = 0;
-        float lo = 0.f, hi = 0.f;
-        if (c < n_cand) {
-            const uint32_t s = s0 + (c >> 1);
-            const uint32_t root = c & 1u;
-            const int16_t *p = pts + 2u * (size_t)seg_p0[s];
-            // i16 -> f32 (render_glyph.zig:43-45)
-            const float p0x = (float)p[0], p0y = (float)p[1];
-            const float p1x = (float)p[2], p1y = (float)p[3];
-            const float p2x = (float)p[4], p2y = (float)p[5];
-            const float a = p0y - 2 * p1y + p2y;                 // :48
-            r.ax = p0x - 2 * p1x + p2x;                          // :53/:65
-            r.bx = 2 * (p1x - p0x);
-            r.p0x = p0x;
-            if (a == 0.0f) {                                     // :49
-                if (root == 0u && p2y != p0y) {                  // :50
-                    r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
-                    r.rden = 1.0f / r.c1;
-                    r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
-                    valid = true;
-                }
-            } else {
-                r.a = a; r.b = p0y - p1y; r.c1 = p1y * p1y; r.c2 = p0y * p2y;    // :58, :60
-                r.rden = 1.0f / a;
-                r.flags = root ? REC_NEG_ROOT : 0u;
-                valid = true;
-            }
-            if (valid) valid = accept_bracket(r, p0y, p2y, lo, hi);
-        }
+        if (c < n_cand) valid = build_record(pts + 2u * (size_t)seg_p0[s0 + (c >> 1)], c & 1u, r);
         const unsigned long long m = __ballot(valid);
         if (valid) {
             const uint32_t pos = n_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            r.lo = lo; r.hi = hi;
             out_recs[out_base + pos] = r;
         }
         n_out += (uint32_t)__popcll(m);

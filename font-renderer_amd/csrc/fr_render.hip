@@ -28,7 +28,7 @@
 //            16 output bytes, one coalesced 16-B store per lane (256 B per row run).
 // Per-pixel work is O(crossings of its row), not O(segments).  A row with more than CAP
 // crossings falls back to the direct sum over records (same integers, slower).
-#include "fr_device.hpp"
+#include "fr_records.hpp"
 
 namespace fr {
 
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 
     const uint32_t g = job.glyph;
     const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[g];
-    const uint32_t rec_cnt = A.glyph_rec_count[g];
+    // fused: one slot per candidate root (2 per segment); else the compacted count of prepare_kernel
+    const uint32_t rec_cnt = A.fused ? 2u * (A.glyph_seg_start[g + 1] - A.glyph_seg_start[g]) : A.glyph_rec_count[g];
 
     // LDS: padded cx table | staged records (<= 256, read-only while waves walk them) |
     //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
@@ -156,9 +157,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
     uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * PROWS_S; // [PROWS_S]
 
-    // stage the first (usually only) 256-record chunk: one record per lane, issued first so the
-    // latency hides under the cx-table divisions
-    if (tid < min(rec_cnt, RCHUNK)) s_rec[tid] = grec[tid];
+    if (A.fused) {
+        // build my glyph's root records straight into LDS (candidate tid = root tid&1 of segment
+        // tid>>1; plans are fused only when every glyph has <= 128 segments): no separate
+        // prepare pass, no record traffic through HBM.  Slots of non-existent / provably empty
+        // roots hold an empty interval and never pass a cull.
+        const uint32_t s0g = A.glyph_seg_start[g];
+        if (tid < rec_cnt) {
+            Rec r;
+            if (!build_record(A.pts + 2u * (size_t)A.seg_p0[s0g + (tid >> 1)], tid & 1u, r)) {
+                r.lo = __builtin_inff(); r.hi = -__builtin_inff();
+                r.a = 1.f; r.b = 0.f; r.c1 = 0.f; r.c2 = 0.f; r.ax = 0.f; r.bx = 0.f; r.p0x = 0.f; r.flags = 0; r.rden = 1.f; r.pad1 = 0;
+            }
+            s_rec[tid] = r;
+        }
+    } else {
+        // stage the first (usually only) 256-record chunk: one record per lane, issued first so
+        // the latency hides under the cx-table divisions
+        if (tid < min(rec_cnt, RCHUNK)) s_rec[tid] = grec[tid];
+    }
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;

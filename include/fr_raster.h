@@ -129,7 +129,10 @@ int fr_glyphset_stats(const fr_glyphset *gs, uint64_t *n_segments, uint64_t *n_r
 int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
                    const fr_raster_params *params, fr_plan **out);
 void fr_plan_destroy(fr_plan *plan);
-/* Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
+/* Every render starts from the glyph POINTS (nothing derived is reused between renders): when
+ * all glyphs of the set have <= 128 segments the render kernel builds each glyph's root records
+ * itself, in LDS ("fused"); otherwise the precompute kernel is re-run first.
+ * Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
  * out_rows rows of out_stride elements (u8, or i16 for FR_WINDING_I16); every job
  * must fit inside it (checked).  Pixels outside all jobs are not touched.           */
 int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows);
