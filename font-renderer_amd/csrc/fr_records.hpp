@@ -46,8 +46,11 @@ __device__ __forceinline__ int classify(const Rec &r, float cy)
 // Smallest key k in [L, H] such that class(k) >= T, given the invariant
 //   every key <  L has class <  T,   every key >= H has class >= T      (class is monotone).
 // Only used when the cheap probes leave a side unbounded (rare): exponential, then bisection.
-__device__ __noinline__ uint32_t first_at_least(const Rec &r, int T, uint32_t L, uint32_t H)
+__device__ __noinline__ uint32_t first_at_least(float ra, float rb, float rc1, float rc2, uint32_t rflags, int T, uint32_t L, uint32_t H)
 {
+    // by value: passing the record by reference to a non-inlined function would force it into scratch
+    Rec r;
+    r.a = ra; r.b = rb; r.c1 = rc1; r.c2 = rc2; r.flags = rflags;
     uint32_t step = 1u;
     while (step < (1u << 30) && H - L > 2u * step) {
         const uint32_t pl = L + step - 1u;
@@ -81,26 +84,26 @@ __device__ inline bool accept_bracket(const Rec &r, float p0y, float p2y, float 
     };
     // width of one rounding plateau of cy*a + c1 near the glyph: ulp(max|c1|,|c2|) / |a|
     float w = 0.0f;
-    float cand[3];
-    int ncand = 2;
-    cand[0] = p0y; cand[1] = p2y;
-    if (!(r.flags & REC_LINEAR)) {
-        cand[2] = p0y - (r.b * r.b) / r.a;                                    // vertex: y(B/a)
-        ncand = 3;
+    float vert = 0.0f;
+    const bool quad = !(r.flags & REC_LINEAR);
+    if (quad) {
+        vert = p0y - (r.b * r.b) / r.a;                                       // vertex: y(B/a)
         const float big = fmaxf(fmaxf(fabsf(r.c1), fabsf(r.c2)), 1.0f);
         w = (big * 1.1920929e-07f) / fabsf(r.a);                              // ~ulp(big)/|a|
     }
-    for (int i = 0; i < ncand; ++i) {
-        const float c = cand[i];
+    auto probe3 = [&](float c) {
         const float d = fmaxf(4.0f * w, fabsf(c) * 4.76837158e-07f);          // >= 4 plateaus, >= 4 ulp
         probe(c - d);
         probe(c);
         probe(c + d);
-    }
+    };
+    probe3(p0y);                                     // (no array, no dynamic index: stays in registers)
+    probe3(p2y);
+    if (quad) probe3(vert);
     if (LB >= HB) return false;                          // class 0 up to LB-1, class 2 from HB: never accepted
     // a side the probes did not bound (no class-0 / class-2 probe at all): settle it exactly
-    if (LB == kmin) LB = first_at_least(r, 1, kmin, HB);
-    if (HB == kmax + 1u) HB = first_at_least(r, 2, LB, kmax + 1u);
+    if (LB == kmin) LB = first_at_least(r.a, r.b, r.c1, r.c2, r.flags, 1, kmin, HB);
+    if (HB == kmax + 1u) HB = first_at_least(r.a, r.b, r.c1, r.c2, r.flags, 2, LB, kmax + 1u);
     if (LB >= HB) return false;
     (void)seen1;
     lo = key2f(LB);
