@@ -330,6 +330,10 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         const fr_job &jb = jobs[j];
         if (jb.glyph >= gs->n_glyphs) return fail(FR_E_INVALID, "job %u: glyph %u of %u", j, jb.glyph, gs->n_glyphs);
         if (!(jb.scale > 0.0f) || !std::isfinite(jb.scale)) return fail(FR_E_INVALID, "job %u: scale must be finite and > 0", j);
+        // keeps every ray height, quotient and FMA residual of div_by_int inside the normal range
+        // (the reference's own scale = u16 / u16 lies in [2^-16, 2^16])
+        if (jb.scale < 9.5367431640625e-07f || jb.scale > 1048576.0f)
+            return fail(FR_E_UNSUPPORTED, "job %u: scale outside [2^-20, 2^20]", j);
         if (jb.w > 65535u || jb.h > 65535u) return fail(FR_E_UNSUPPORTED, "job %u: cell larger than 65535", j);
         // sample coordinates must be exactly representable in binary32
         if (jb.min_x < -(1 << 22) || (int64_t)jb.min_x + jb.w > (1 << 22) || jb.max_y > (1 << 22) ||
