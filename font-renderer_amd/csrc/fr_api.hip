@@ -83,7 +83,8 @@ struct fr_plan {
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
     unsigned long long *d_ovf_bits = nullptr;
-    uint32_t *d_ovf_count = nullptr;
+    uint32_t *d_ovf_count = nullptr;    // two counters, used alternately
+    uint32_t render_parity = 0;
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
@@ -368,6 +369,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(&p->d_ovf_bits, ((size_t)n_jobs * p->bands * p->strips + 1) * 8);
     if (e == hipSuccess) e = hipMalloc(&p->d_ovf_count, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_ovf_count, 0, 16, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -413,13 +415,14 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.bands_per_wg = bpw;
     a.band_groups = (plan->bands + bpw - 1) / bpw;
     a.ovf_bits = plan->d_ovf_bits;
-    a.ovf_count = plan->d_ovf_count;
+    a.ovf_count = plan->d_ovf_count + (plan->render_parity & 1u);
+    a.ovf_count_next = plan->d_ovf_count + ((plan->render_parity + 1u) & 1u);
+    plan->render_parity ^= 1u;
     HIP_TRY(hipSetDevice(plan->ctx->device));
     if (plan->params.mode == FR_SDF_U8) {
         HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
         return FR_OK;
     }
-    HIP_TRY(hipMemsetAsync(plan->d_ovf_count, 0, 4, plan->ctx->stream));
     // a render always starts from the glyph POINTS: either inside the render kernel (fused) or by
     // re-running the stand-alone precompute first
     if (!a.fused)

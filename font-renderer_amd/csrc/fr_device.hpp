@@ -72,7 +72,8 @@ struct RenderArgs {
     uint32_t fused;
     void *out;
     unsigned long long *ovf_bits;      // [n_jobs][bands][strips]: over-full sample rows of each wave band
-    uint32_t *ovf_count;               // number of wave bands with any (zeroed before each render)
+    uint32_t *ovf_count;               // number of wave bands with any; ping-pong pair: this render counts in
+    uint32_t *ovf_count_next;          // ovf_count and zeroes ovf_count_next for the following render
     uint64_t out_stride;               // elements
     uint32_t n_jobs, bands, strips, strip_w, kmax;
     uint32_t bands_per_wg, band_groups;   // a workgroup walks bands_per_wg consecutive bands of its cell

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * A.strip_w;
     const uint32_t band_first = bgrp * A.bands_per_wg;          // in wave bands
+    if (blockIdx.x == 0 && tid == 0) *A.ovf_count_next = 0u;     // (saves a memset node per render)
     if (band_first * WBAND >= job.h || x0s >= job.w) return;    // workgroup-uniform
     const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + WBAND - 1u) / WBAND);
     const uint32_t sw = min(A.strip_w, job.w - x0s);            // strip width, pixels
@@ -364,8 +365,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             e[8 * q + 0] = v.x & 0xffffu; e[8 * q + 1] = v.x >> 16; e[8 * q + 2] = v.y & 0xffffu; e[8 * q + 3] = v.y >> 16;
             e[8 * q + 4] = v.z & 0xffffu; e[8 * q + 5] = v.z >> 16; e[8 * q + 6] = v.w & 0xffffu; e[8 * q + 7] = v.w >> 16;
         }
-        if (CAP > 16 && __ballot(cnt > 16u) != 0ull) sort_network<32>(e);
-        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) sort_network<16>(e);
+        // the generator handles any width: 5 tiers keep the comparator count near the need
+        if (CAP > 24 && __ballot(cnt > 24u) != 0ull) sort_network<32>(e);
+        else if (CAP > 16 && __ballot(cnt > 16u) != 0ull) sort_network<24>(e);
+        else if (CAP > 12 && __ballot(cnt > 12u) != 0ull) sort_network<16>(e);
+        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) sort_network<12>(e);
         else sort_network<8>(e);
     }
     wave_lds_sync();                            // the list region becomes the mask region below
