@@ -50,6 +50,10 @@ __device__ __forceinline__ float bcast(float v, uint32_t k)
 #endif
 // One crossing = 16 bits: (J << 1) | (sign > 0), J <= 2048 sample columns; 0xffff = no crossing.
 constexpr uint32_t EMPTY = 0xffffu;
+#ifndef FR_DENSE_WALK
+#define FR_DENSE_WALK 1
+#endif
+constexpr uint32_t PCAP = 1024u;               // (record,row) pairs buffered per wave before a dense evaluation round
 constexpr uint32_t LSTRIDE = 40u;              // u16 slots per row list: 32 used + pad; an 80-byte
                                                // row stride makes one-row-per-lane b128 reads conflict-free
 
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     // my row's crossings are APPENDED to a wave-private LDS list during the walk (one
     // ds_write_b16 each) and sorted once afterwards; the list lives where the window masks
     // will be (they are built after the list has been pulled into registers)
-    uint16_t *mylist = reinterpret_cast<uint16_t *>(wregion) + lane * LSTRIDE;
+    uint16_t *s_lists = reinterpret_cast<uint16_t *>(wregion);                         // [64][LSTRIDE]
+    uint16_t *mylist = s_lists + lane * LSTRIDE;
     {
         uint4 *f = reinterpret_cast<uint4 *>(mylist);
         const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
@@ -221,6 +226,72 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         for (uint32_t q = 0; q < CAP / 8u; ++q) f[q] = ones;       // all EMPTY
     }
     uint32_t cnt = 0;
+#if FR_DENSE_WALK
+    // dense walk: the wave first collects every (record, row) pair that passes the bracket test
+    // (ballot + prefix popcount -> a packed LDS list), then ALL 64 lanes evaluate pairs — a lane
+    // works for whichever row its pair names and appends the crossing to that row's list through
+    // an LDS counter.  No lane idles while a record is live on only a few rows.
+    uint16_t *s_pairs = s_lists + 64u * LSTRIDE;                                       // [PCAP]: rec << 6 | row
+    float *s_cy = reinterpret_cast<float *>(s_pairs + PCAP);                          // [64]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_cy + 64);                         // [64]
+    s_cy[lane] = cy;
+    s_cnt[lane] = 0u;
+    uint32_t npairs = 0;                        // wave-uniform
+    const float cy_scan = row_valid ? cy : __builtin_nanf("");
+    auto eval_pairs = [&]() {
+        wave_lds_sync();
+        for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
+            const uint32_t p = p0 + lane;
+#if defined(FR_ABLATE) && FR_ABLATE == 10
+            if (p < npairs && A.n_jobs == 0xffffffffu) {    // timing-only: pairs are collected, never evaluated
+#else
+            if (p < npairs) {
+#endif
+                const uint32_t pr = s_pairs[p];
+                const uint32_t row = pr & 63u;
+                const Rec r = s_rec[pr >> 6];
+                const float cyr = s_cy[row];
+                // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
+                const bool lin = (r.flags & REC_LINEAR) != 0;
+                const float delta = cyr * r.a + r.c1 - r.c2;
+                const float sq = __builtin_sqrtf(delta);
+                const float num = lin ? (cyr - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));
+                const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);     // == num / d, see fr_device.hpp
+                // [lo, hi] brackets the accepted set; the reference's own tests decide (:52, :59, :64)
+                const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
+                const float xx = (r.ax * t + r.bx) * t + r.p0x;
+                const float dy = r.a * t + (-r.b);
+                const int sgn = lin ? ((r.flags & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
+                // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
+                float gf = xx * jscale - joff;
+                gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
+                int J = (int)gf;
+                {
+#if defined(FR_ABLATE) && FR_ABLATE == 11
+                    const float c0 = xx, c1 = xx + 1.0f;             // timing-only: no table look-up
+#else
+                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];    // one ds_read2_b32
+#endif
+                    const bool good = (c0 <= xx) & (xx < c1);
+                    if (!good) {
+                        while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
+                        while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
+                    }
+                }
+#if defined(FR_ABLATE) && FR_ABLATE == 12
+                if (accepted && J > 0 && A.n_jobs == 0xffffffffu) {  // timing-only: evaluated, never appended
+#else
+                if (accepted && J > 0) {
+#endif
+                    const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
+                    if (pos < (uint32_t)CAP) s_lists[row * LSTRIDE + pos] = (uint16_t)(((uint32_t)J << 1) | (sgn > 0 ? 1u : 0u));
+                }
+            }
+        }
+        wave_lds_sync();
+        npairs = 0;
+    };
+#endif
 
     for (uint32_t base = 0; base < rec_cnt; base += RCHUNK) {
         if (rec_cnt > RCHUNK) {                   // multi-chunk glyph: restage (workgroup-uniform path)
@@ -281,6 +352,29 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             taken = false;
             occ = 0;
         };
+#if FR_DENSE_WALK
+        for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
+            const uint32_t mi = min(cb + lane, nchunk - 1u);
+            const float mlo = s_rec[mi].lo, mhi = s_rec[mi].hi;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64((cb + lane < nchunk) & (mhi >= wcy_bot) & (mlo <= wcy_top));
+            while (todo) {
+                const uint32_t kk = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t k = cb + kk;
+                todo &= todo - 1ull;
+                // the record's bounds come from the lane that already holds them (v_readlane): no
+                // LDS round trip on the scan's critical path
+                const float klo = bcast(mlo, kk), khi = bcast(mhi, kk);
+                const bool want = (cy_scan >= klo) & (cy_scan <= khi);       // NaN for rows past the band
+                const unsigned long long wl = __builtin_amdgcn_ballot_w64(want);
+                if (!wl) continue;
+                const uint32_t nw = (uint32_t)__popcll(wl);
+                if (npairs + nw > PCAP) eval_pairs();
+                if (want) s_pairs[npairs + (uint32_t)__popcll(wl & ((1ull << lane) - 1ull))] = (uint16_t)((k << 6) | lane);
+                npairs += nw;
+            }
+        }
+        if (npairs) eval_pairs();               // before the staged records are replaced / the band ends
+#else
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
             // my lane's record of this 64-chunk: only its bounds are needed, for the wave-level cull
             const uint32_t mi = min(cb + lane, nchunk - 1u);
@@ -316,7 +410,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             }
         }
         if (occ) { COUNT(6, 1); flush(); }
+#endif
     }
+#if FR_DENSE_WALK
+    cnt = s_cnt[lane];
+#endif
     COUNT(4, 1);                                // wave bands
     STAMP(1);                                   // phase 1: record walk
     if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
@@ -641,7 +739,8 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
     const size_t prow = 64u / FR_BAND_PARTS;
     size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
-    if (wb < 64u * LSTRIDE * 2u) wb = 64u * LSTRIDE * 2u;     // the crossing lists of the walk live here first
+    const size_t walk = 64u * LSTRIDE * 2u + (FR_DENSE_WALK ? PCAP * 2u + 64u * 8u : 0u);   // lists (+ pairs, cy, counters)
+    if (wb < walk) wb = walk;                                  // the walk's buffers live here first
     const size_t rb = (size_t)RCHUNK * sizeof(Rec);
     const size_t t = cx + rb + 4 * wb;
     *rec_bytes = (uint32_t)rb;
