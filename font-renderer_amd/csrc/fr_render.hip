@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #else
         const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
 #endif
+#if !FR_DENSE_WALK
         // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane.
         // Neighbouring segments of a contour stack vertically, so consecutive records are live
         // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             taken = false;
             occ = 0;
         };
+#endif
 #if FR_DENSE_WALK
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
             const uint32_t mi = min(cb + lane, nchunk - 1u);
@@ -367,10 +369,9 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const bool want = (cy_scan >= klo) & (cy_scan <= khi);       // NaN for rows past the band
                 const unsigned long long wl = __builtin_amdgcn_ballot_w64(want);
                 if (!wl) continue;
-                const uint32_t nw = (uint32_t)__popcll(wl);
-                if (npairs + nw > PCAP) eval_pairs();
+                if (npairs > PCAP - 64u) eval_pairs();                      // a record adds at most 64 pairs
                 if (want) s_pairs[npairs + (uint32_t)__popcll(wl & ((1ull << lane) - 1ull))] = (uint16_t)((k << 6) | lane);
-                npairs += nw;
+                npairs += (uint32_t)__popcll(wl);
             }
         }
         if (npairs) eval_pairs();               // before the staged records are replaced / the band ends
