@@ -45,14 +45,45 @@ __device__ __forceinline__ float bcast(float v, uint32_t k)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)k));
 }
 
+// wave64 inclusive scans on DPP (row_shr within the 16-lane rows, then row_bcast:15 / :31 carry
+// the row totals across rows): 6 VALU operations, no LDS.  `old` = 0 is the identity of both.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t x)
+{
+    x += dpp0<0x111, 0xf>(x);                   // row_shr:1
+    x += dpp0<0x112, 0xf>(x);                   // row_shr:2
+    x += dpp0<0x114, 0xf>(x);                   // row_shr:4
+    x += dpp0<0x118, 0xf>(x);                   // row_shr:8
+    x += dpp0<0x142, 0xa>(x);                   // row_bcast:15 -> rows 1, 3
+    x += dpp0<0x143, 0xc>(x);                   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x)
+{
+    x = max(x, dpp0<0x111, 0xf>(x));
+    x = max(x, dpp0<0x112, 0xf>(x));
+    x = max(x, dpp0<0x114, 0xf>(x));
+    x = max(x, dpp0<0x118, 0xf>(x));
+    x = max(x, dpp0<0x142, 0xa>(x));
+    x = max(x, dpp0<0x143, 0xc>(x));
+    return x;
+}
+
 #ifndef FR_BAND_PARTS
-#define FR_BAND_PARTS 2
+#define FR_BAND_PARTS 1
+#endif
+// 2: every record carries its exact sample-row range; a band's (record, row) pairs are laid out
+//    by a prefix sum and decoded by a marker + max-scan (load-balanced expansion, no per-record loop)
+// 1: per-record ballot scan against [lo, hi] (previous scheme, kept for A/B timing)
+#ifndef FR_WALK
+#define FR_WALK 2
 #endif
 // One crossing = 16 bits: (J << 1) | (sign > 0), J <= 2048 sample columns; 0xffff = no crossing.
 constexpr uint32_t EMPTY = 0xffffu;
-#ifndef FR_DENSE_WALK
-#define FR_DENSE_WALK 1
-#endif
 constexpr uint32_t PCAP = 1024u;               // (record,row) pairs buffered per wave before a dense evaluation round
 constexpr uint32_t LSTRIDE = 40u;              // u16 slots per row list: 32 used + pad; an 80-byte
                                                // row stride makes one-row-per-lane b128 reads conflict-free
@@ -81,23 +112,32 @@ constexpr uint32_t RCHUNK = 256u;
 // sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
 // library is built without FR_STAMPS and executes no stamp.
 #ifdef FR_STAMPS
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];
 #define STAMP(i)                                                                          \
     do {                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
         unsigned long long t_;                                                            \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
         __builtin_amdgcn_sched_barrier(0);                                                \
-        if (tid == 0) atomicAdd(&g_stamps[i], t_ - t_prev_);                              \
+        acc_[i] += t_ - t_prev_;                                                          \
         t_prev_ = t_;                                                                     \
     } while (0)
 #define STAMP_INIT()                                                                      \
-    unsigned long long t_prev_;                                                           \
+    unsigned long long t_prev_, acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cacc_[4] = {0, 0, 0, 0}; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_)::"memory")
-#define COUNT(i, n) do { if (lane == 0) atomicAdd(&g_stamps[i], (unsigned long long)(n)); } while (0)
+// one atomic per phase per workgroup (wave 0), at the very end: the stamps themselves stay cheap
+#define STAMP_FLUSH()                                                                     \
+    do {                                                                                  \
+        if (tid == 0)                                                                     \
+            for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[i_], acc_[i_]);            \
+        if (lane == 0)                                                                    \
+            for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&g_stamps[8 + i_], cacc_[i_]);       \
+    } while (0)
+#define COUNT(i, n) do { cacc_[(i) - 8] += (unsigned long long)(n); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #define STAMP_INIT() do {} while (0)
+#define STAMP_FLUSH() do {} while (0)
 #define COUNT(i, n) do {} while (0)
 #endif
 
@@ -162,6 +202,33 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
     uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * PROWS_S; // [PROWS_S]
 
+    // Every staged record swaps its bracket [lo, hi] (ray heights) for the EXACT half-open range
+    // [ra, re) of this cell's sample rows whose cy lies in it — cy(r) is non-increasing in r, so
+    // the range is one interval: ra = min{ r : cy(r) <= hi }, re = min{ r : cy(r) < lo }.  A guess
+    // from the affine map is settled against the exact cy(r) (the expression of :27).
+    const uint32_t Hs = job.h * (uint32_t)N;    // sample rows of the cell
+    auto cy_of = [&](uint32_t r) -> float {
+        return ((float)(job.max_y - (int32_t)(r / N)) - sub_off((int)(r % N), N, phase)) / job.scale;
+    };
+    auto stage = [&](Rec r) {
+#if FR_WALK == 2
+        uint32_t ra = 1u, re = 0u;
+        if (r.lo <= r.hi) {
+            const float ph = phase ? 0.5f : 0.0f, top = (float)(Hs - 1u);
+            const float ga = ((float)job.max_y - r.hi * job.scale) * (float)N - ph;
+            const float ge = ((float)job.max_y - r.lo * job.scale) * (float)N - ph;
+            ra = (uint32_t)fminf(fmaxf(ga, 0.0f), top);
+            re = (uint32_t)fminf(fmaxf(ge, 0.0f), top);
+            while (ra > 0u && cy_of(ra - 1u) <= r.hi) --ra;
+            while (ra < Hs && cy_of(ra) > r.hi) ++ra;
+            while (re > 0u && cy_of(re - 1u) < r.lo) --re;
+            while (re < Hs && cy_of(re) >= r.lo) ++re;
+        }
+        r.lo = __builtin_bit_cast(float, ra);
+        r.hi = __builtin_bit_cast(float, re);
+#endif
+        return r;
+    };
     if (A.fused) {
         // build my glyph's root records straight into LDS (candidate tid = root tid&1 of segment
         // tid>>1; plans are fused only when every glyph has <= 128 segments): no separate
@@ -174,12 +241,12 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 r.lo = __builtin_inff(); r.hi = -__builtin_inff();
                 r.a = 1.f; r.b = 0.f; r.c1 = 0.f; r.c2 = 0.f; r.ax = 0.f; r.bx = 0.f; r.p0x = 0.f; r.flags = 0; r.rden = 1.f; r.pad1 = 0;
             }
-            s_rec[tid] = r;
+            s_rec[tid] = stage(r);
         }
     } else {
         // stage the first (usually only) 256-record chunk: one record per lane, issued first so
         // the latency hides under the cx-table divisions
-        if (tid < min(rec_cnt, RCHUNK)) s_rec[tid] = grec[tid];
+        if (tid < min(rec_cnt, RCHUNK)) s_rec[tid] = stage(grec[tid]);
     }
 
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
@@ -210,9 +277,11 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     const bool row_valid = lane < nrows;
     const uint32_t rr0 = row_valid ? lane : 0u;
     const float cy = ((float)(job.max_y - (int32_t)(y0 + rr0 / N)) - sub_off((int)(rr0 % N), N, phase)) / job.scale;
+#if FR_WALK != 2
     // cy is non-increasing in the row index: this wave spans [wcy_bot, wcy_top]
     const float wcy_top = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
     const float wcy_bot = bcast(cy, nrows ? nrows - 1u : 0u);
+#endif
 
     // my row's crossings are APPENDED to a wave-private LDS list during the walk (one
     // ds_write_b16 each) and sorted once afterwards; the list lives where the window masks
@@ -226,30 +295,58 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         for (uint32_t q = 0; q < CAP / 8u; ++q) f[q] = ones;       // all EMPTY
     }
     uint32_t cnt = 0;
-#if FR_DENSE_WALK
-    // dense walk: the wave first collects every (record, row) pair that passes the bracket test
-    // (ballot + prefix popcount -> a packed LDS list), then ALL 64 lanes evaluate pairs — a lane
-    // works for whichever row its pair names and appends the crossing to that row's list through
-    // an LDS counter.  No lane idles while a record is live on only a few rows.
-    uint16_t *s_pairs = s_lists + 64u * LSTRIDE;                                       // [PCAP]: rec << 6 | row
+    // dense walk: the wave first lays out every (record, row) pair of the band, then ALL 64 lanes
+    // evaluate pairs — a lane works for whichever row its pair names and appends the crossing to
+    // that row's list through an LDS counter.  No lane idles while a record is live on only a
+    // few rows.
+    uint16_t *s_pairs = s_lists + 64u * LSTRIDE;                                       // [PCAP]
     float *s_cy = reinterpret_cast<float *>(s_pairs + PCAP);                          // [64]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_cy + 64);                         // [64]
+    int16_t *s_roff = reinterpret_cast<int16_t *>(s_cnt + 64);                         // [RCHUNK]
     s_cy[lane] = cy;
     s_cnt[lane] = 0u;
     uint32_t npairs = 0;                        // wave-uniform
+#if FR_WALK == 2
+    // s_pairs holds MARKERS: slot `off` of the pair sequence holds k + 1 where record k's run of
+    // pairs starts, 0 elsewhere; a max-scan over the slots recovers every pair's record
+    auto zero_markers = [&]() {
+        uint4 *mz = reinterpret_cast<uint4 *>(s_pairs);
+        for (uint32_t q = lane; q < PCAP / 8u; q += 64u) mz[q] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();                        // (also orders these 16-B stores before the 2-B marker stores)
+    };
+    zero_markers();
+    const uint32_t row_b0 = band * 64u;         // first sample row of my band (global in the cell)
+#else
     const float cy_scan = row_valid ? cy : __builtin_nanf("");
+#endif
     auto eval_pairs = [&]() {
         wave_lds_sync();
+        STAMP(1);                               // pair layout
+        COUNT(9, npairs);
+#if FR_WALK == 2
+        uint32_t carry = 0;
+#endif
         for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
             const uint32_t p = p0 + lane;
+#if FR_WALK == 2
+            const uint32_t mk = (p < npairs) ? (uint32_t)s_pairs[p] : 0u;
+            const uint32_t k1 = max(wave_incl_max(mk), carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
+#endif
 #if defined(FR_ABLATE) && FR_ABLATE == 10
             if (p < npairs && A.n_jobs == 0xffffffffu) {    // timing-only: pairs are collected, never evaluated
 #else
             if (p < npairs) {
 #endif
+#if FR_WALK == 2
+                const uint32_t kk = k1 - 1u;
+                const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]);
+                const Rec r = s_rec[kk];
+#else
                 const uint32_t pr = s_pairs[p];
                 const uint32_t row = pr & 63u;
                 const Rec r = s_rec[pr >> 6];
+#endif
                 const float cyr = s_cy[row];
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (r.flags & REC_LINEAR) != 0;
@@ -257,12 +354,14 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const float sq = __builtin_sqrtf(delta);
                 const float num = lin ? (cyr - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));
                 const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);     // == num / d, see fr_device.hpp
-                // [lo, hi] brackets the accepted set; the reference's own tests decide (:52, :59, :64)
+                // the row range brackets the accepted set; the reference's own tests decide (:52, :59, :64)
                 const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
                 const float xx = (r.ax * t + r.bx) * t + r.p0x;
                 const float dy = r.a * t + (-r.b);
                 const int sgn = lin ? ((r.flags & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
                 // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
+                // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
+                // map, confirm with one paired read, walk only if the guess is off
                 float gf = xx * jscale - joff;
                 gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
                 int J = (int)gf;
@@ -272,7 +371,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #else
                     const float c0 = s_cxp[J], c1 = s_cxp[J + 1];    // one ds_read2_b32
 #endif
-                    const bool good = (c0 <= xx) & (xx < c1);
+                    const bool good = (c0 <= xx) & (xx < c1);        // '&': both loads issue together
                     if (!good) {
                         while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
                         while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
@@ -290,13 +389,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         }
         wave_lds_sync();
         npairs = 0;
+        STAMP(2);                               // pair evaluation
     };
-#endif
 
     for (uint32_t base = 0; base < rec_cnt; base += RCHUNK) {
         if (rec_cnt > RCHUNK) {                   // multi-chunk glyph: restage (workgroup-uniform path)
             __syncthreads();
-            if (tid < RCHUNK && base + tid < rec_cnt) s_rec[tid] = grec[base + tid];
+            if (tid < RCHUNK && base + tid < rec_cnt) s_rec[tid] = stage(grec[base + tid]);
             __syncthreads();
         }
 #if defined(FR_ABLATE) && FR_ABLATE == 8
@@ -304,57 +403,33 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #else
         const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
 #endif
-#if !FR_DENSE_WALK
-        // ---- phase 1: crossings of my sample row; records travel lane -> wave by readlane.
-        // Neighbouring segments of a contour stack vertically, so consecutive records are live
-        // on DISJOINT lanes: each lane latches the record that accepted it (v_cndmask from the
-        // broadcast) and the wave evaluates many records in ONE pass; a pass is flushed only
-        // when the next record wants a lane that is already taken.
-        float sa = 0.f, sb = 0.f, sc1 = 0.f, sc2 = 0.f, sax = 0.f, sbx = 0.f, sp0x = 0.f, srd = 0.f;
-        uint32_t sfl = 0;
-        bool taken = false;                     // this lane holds a latched record
-        unsigned long long occ = 0;             // lanes holding one (wave-uniform)
-        auto flush = [&]() {
-#if defined(FR_ABLATE) && FR_ABLATE == 5
-            if (taken && sfl == 0x12345u) {      // timing-only: no evaluation at all
-#else
-            if (taken) {
-#endif
-                // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
-                const bool lin = (sfl & REC_LINEAR) != 0;
-                const float delta = cy * sa + sc1 - sc2;
-                const float sq = __builtin_sqrtf(delta);
-                const float num = lin ? (cy - sb) : ((sfl & REC_NEG_ROOT) ? (sb - sq) : (sb + sq));
-                const float t = div_by_int(num, lin ? sc1 : sa, srd);      // == num / d, see fr_device.hpp
-                // [lo, hi] brackets the accepted set; the reference's own tests decide (:52, :59, :64)
-                const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
-                const float xx = (sax * t + sbx) * t + sp0x;
-                const float dy = sa * t + (-sb);
-                const int sgn = lin ? ((sfl & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
-                // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
-                // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
-                // map, confirm with one paired read, walk only if the guess is off
-                float gf = xx * jscale - joff;
-                gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
-                int J = (int)gf;
-                {
-                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];    // one ds_read2_b32
-                    const bool good = (c0 <= xx) & (xx < c1);        // '&': both loads issue together
-                    if (!good) {
-                        while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
-                        while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
-                    }
+#if FR_WALK == 2
+        for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
+            // lane = record: clip its row range to my band, prefix-sum the run lengths
+            const uint32_t k = cb + lane;
+            const uint32_t mi = min(k, nchunk - 1u);
+            const uint32_t ra = __builtin_bit_cast(uint32_t, s_rec[mi].lo), re = __builtin_bit_cast(uint32_t, s_rec[mi].hi);
+            const uint32_t r0 = max(ra, row_b0), r1 = min(re, row_b0 + nrows);
+            const uint32_t c = (k < nchunk && r1 > r0) ? r1 - r0 : 0u;
+            unsigned long long pending = __builtin_amdgcn_ballot_w64(c != 0u);
+            while (pending) {
+                const uint32_t cc = ((pending >> lane) & 1ull) ? c : 0u;
+                const uint32_t incl = wave_incl_add(cc);
+                // runs that still fit the pair buffer (a prefix of the pending ones: incl is monotone)
+                const bool fit = (cc != 0u) & (npairs + incl <= PCAP);
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(fit);
+                if (fit) {
+                    const uint32_t off = npairs + incl - cc;
+                    s_pairs[off] = (uint16_t)(k + 1u);
+                    s_roff[k] = (int16_t)((int32_t)(r0 - row_b0) - (int32_t)off);
                 }
-                if (accepted && J > 0) {
-                    if (cnt < (uint32_t)CAP) mylist[cnt] = (uint16_t)(((uint32_t)J << 1) | (sgn > 0 ? 1u : 0u));
-                    ++cnt;
-                }
+                if (fm) npairs += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - (int)__builtin_clzll(fm));
+                pending &= ~fm;
+                if (pending) { eval_pairs(); zero_markers(); }      // buffer full: evaluate, then go on
             }
-            taken = false;
-            occ = 0;
-        };
-#endif
-#if FR_DENSE_WALK
+        }
+        if (npairs) { eval_pairs(); if (base + RCHUNK < rec_cnt) zero_markers(); }   // before the staged records are replaced / the band ends
+#else
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
             const uint32_t mi = min(cb + lane, nchunk - 1u);
             const float mlo = s_rec[mi].lo, mhi = s_rec[mi].hi;
@@ -375,49 +450,12 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             }
         }
         if (npairs) eval_pairs();               // before the staged records are replaced / the band ends
-#else
-        for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
-            // my lane's record of this 64-chunk: only its bounds are needed, for the wave-level cull
-            const uint32_t mi = min(cb + lane, nchunk - 1u);
-            const float mlo = s_rec[mi].lo, mhi = s_rec[mi].hi;
-            // records of this 64-chunk whose interval meets THIS wave's rows: one ballot, then a
-            // scalar find-first-set loop — records that miss the wave cost nothing
-            unsigned long long todo = __ballot((cb + lane < nchunk) && (mhi >= wcy_bot) && (mlo <= wcy_top));
-            // every lane reads the SAME record: an LDS broadcast (operands land in VGPRs); the
-            // read for the next record is issued before the current one is processed
-            Rec rnext = s_rec[cb + (todo ? (uint32_t)__builtin_ctzll(todo) : 0u)];
-            while (todo) {
-                todo &= todo - 1ull;
-                const Rec rk = rnext;
-                if (todo) rnext = s_rec[cb + (uint32_t)__builtin_ctzll(todo)];
-                const bool want = row_valid && cy >= rk.lo && cy <= rk.hi;
-                const unsigned long long wl = __ballot(want);
-                if (!wl) continue;
-                COUNT(5, 1);                    // records that touch the wave
-                COUNT(7, __popcll(wl));         // lanes they are live on
-#if defined(FR_ABLATE) && FR_ABLATE == 6
-                if (wl == 0x1234567ull) {       // timing-only: scan only, no latch, no flush
-#else
-                {
-#endif
-                if (wl & occ) { COUNT(6, 1); flush(); }
-                if (want) {
-                    sa = rk.a; sb = rk.b; sc1 = rk.c1; sc2 = rk.c2; sax = rk.ax; sbx = rk.bx;
-                    sp0x = rk.p0x; srd = rk.rden; sfl = rk.flags;
-                    taken = true;
-                }
-                occ |= wl;
-                }
-            }
-        }
-        if (occ) { COUNT(6, 1); flush(); }
 #endif
     }
-#if FR_DENSE_WALK
     cnt = s_cnt[lane];
-#endif
-    COUNT(4, 1);                                // wave bands
-    STAMP(1);                                   // phase 1: record walk
+    COUNT(8, 1);                                // wave bands
+    COUNT(11, cnt);                             // crossings of lane 0's row (x64 ~ per band)
+    STAMP(1);                                   // pair layout (remainder)
     if (!nrows) continue;                       // this wave has no band in this round (no barriers below)
     if (__ballot(cnt != 0u) == 0ull) {
         // ---- no crossing on any of my 64 sample rows: every winding is 0 — store the band's
@@ -472,6 +510,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         else sort_network<8>(e);
     }
     wave_lds_sync();                            // the list region becomes the mask region below
+    STAMP(3);                                   // list pull + sort
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
     // publish which of my 64 sample rows they are (one word per wave band, always written)
     {
@@ -528,7 +567,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 s_fill[hrow] = fill;
             }
             wave_lds_sync();
-            STAMP(2);                           // phase 1b: zero + toggles
+            STAMP(4);                           // phase 1b: zero + toggles
 
             // ---- phase 2: one lane per 16-pixel window
             const uint32_t wx = lane & (nwin_pad - 1u);
@@ -586,15 +625,21 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                         }
                     }
                     uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + (out_row0 + yl) * A.out_stride + out_col0 + px0;
+#if defined(FR_ABLATE) && FR_ABLATE == 13
+                    if ((pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) == 0x12345678u) {        // timing-only: windows computed, (almost) never stored
+#else
                     if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+#endif
                         *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                     } else {
+#if !(defined(FR_ABLATE) && FR_ABLATE == 13)
                         for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
+#endif
                     }
                 }
             }
             wave_lds_sync();                    // masks are re-zeroed by the next half / band
-            STAMP(3);                           // phase 2: windows + stores
+            STAMP(5);                           // phase 2: windows + stores
         } else {
             // ---- winding-value modes (N == 1): breakpoints (b_i, winding on [b_{i-1}, b_i)) per row
             if (mine_half) {
@@ -669,14 +714,15 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         }
     }   // half band
   }   // band loop
+  STAMP_FLUSH();
 }
 
 #ifdef FR_STAMPS
-extern "C" int fr_debug_read_stamps(unsigned long long *out8, int reset)
+extern "C" int fr_debug_read_stamps(unsigned long long *out16, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
     }
     return e == hipSuccess ? 0 : -2;
@@ -740,7 +786,7 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
     const size_t prow = 64u / FR_BAND_PARTS;
     size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
-    const size_t walk = 64u * LSTRIDE * 2u + (FR_DENSE_WALK ? PCAP * 2u + 64u * 8u : 0u);   // lists (+ pairs, cy, counters)
+    const size_t walk = 64u * LSTRIDE * 2u + PCAP * 2u + 64u * 8u + RCHUNK * 2u;   // lists, pairs / markers, cy, counters, run offsets
     if (wb < walk) wb = walk;                                  // the walk's buffers live here first
     const size_t rb = (size_t)RCHUNK * sizeof(Rec);
     const size_t t = cx + rb + 4 * wb;

@@ -20,15 +20,15 @@ dgs = fr.DeviceGlyphSet(ctx, gs)
 H, W = atlas_shape(G, cell, cols)
 out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
 plan = fr.Plan(dgs, cell_jobs(gs, cell, cell, 2048, cols), fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER)
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 plan.render(out.data_ptr(), W, H); ctx.sync()
 lib.fr_debug_read_stamps(buf, 1)
 plan.render(out.data_ptr(), W, H); ctx.sync()
 lib.fr_debug_read_stamps(buf, 1)
 v = np.array(list(buf), float)
-names = ["setup (stage, cx table)", "phase1 walk (+cy)", "phase1b zero+toggles", "phase2 windows+stores", "-", "-", "-"]
-v4 = v[:4]
-for nme, x in zip(names, v4):
-    print(f"{nme:24s} {x / v4.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup")
-c = np.array(list(buf), float)
-print(f"wave bands {c[4]:.0f}; per wave band: records touching {c[5] / c[4]:.2f}, evaluation passes {c[6] / c[4]:.2f}, live lanes per record {c[7] / max(c[5], 1):.1f}")
+names = ["setup (records, ranges, cx table)", "pair layout", "pair evaluation", "list pull + sort", "zero + toggles", "windows + stores"]
+v6 = v[:6]
+for nme, x in zip(names, v6):
+    print(f"{nme:36s} {x / v6.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup (wave 0)")
+bands = max(v[8], 1)
+print(f"wave bands {v[8]:.0f}; per wave band: pairs {v[9] / bands:.1f}, crossings ~{64 * v[11] / bands:.1f}")
