@@ -142,4 +142,112 @@ __device__ inline bool build_record(const int16_t *p, uint32_t root, Rec &r)
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row form of the same bracket, used by the render kernel's in-LDS record build.  A cell's sample
+// rows have ray heights cy(r) = (f32(max_y - y) - off) / scale (render_glyph.zig:27), non-increasing
+// in r, so by the monotonicity argued above the class of row r is NON-INCREASING in r (2 = above
+// the accepted set, 1 = accepted, 0 = below) and the accepted rows are ONE half-open range
+//        [ra, re),   ra = min{ r : class(r) <= 1 },   re = min{ r >= ra : class(r) == 0 }.
+// Both ends are settled by evaluating the reference's own expression at the rows either side of a
+// guess and walking while the class says so — the guess (where t = 0, t = 1 and delta = 0 sit in
+// exact arithmetic) only decides how many rows are looked at, never the result.  Two candidates
+// are discarded without a probe, by a bound that holds for the rounded values too:
+//   * the root on the far side of a vertex at t_v = B/a >= 1 is >= fl(B/a) >= 1  (always rejected, :64)
+//   * the root on the near side of a vertex at t_v < 0 is <= fl(B/a) < 0          (always rejected, :64)
+// (B +/- sqrt(delta) is >= / <= B after rounding because B is representable, and a correctly
+// rounded division by a is monotone; |B/a| >= 2^-17 cannot round to zero.)
+struct RowGeom {
+    int32_t max_y;
+    float scale;
+    uint32_t rows;       // sample rows of the cell (h * N)
+    int n, phase;
+    __device__ __forceinline__ float cy(uint32_t r) const
+    {
+        return ((float)(max_y - (int32_t)(r / (uint32_t)n)) - sub_off((int)(r % (uint32_t)n), n, phase)) / scale;
+    }
+    // fractional row index at which the ray height equals c (rows r >= x lie at or below c)
+    __device__ __forceinline__ float row_of(float c) const
+    {
+        return ((float)max_y - c * scale) * (float)n - (phase ? 0.5f : 0.0f);
+    }
+};
+
+// branch-free class of ray height cy for either kind of record; t by div_by_int (== IEEE `/`, fr_device.hpp)
+__device__ __forceinline__ int classify_row(const Rec &r, float cy)
+{
+    const bool lin = (r.flags & REC_LINEAR) != 0;
+    const float delta = cy * r.a + r.c1 - r.c2;                                  // :58
+    const float sq = __builtin_sqrtf(delta);
+    const float num = lin ? (cy - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));   // :51 / :60-61
+    const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);
+    // t falls with cy for the t- root and for a descending line
+    const bool falls = lin ? !(r.c1 > 0.0f) : ((r.flags & REC_NEG_ROOT) != 0);
+    int cl = 1;
+    if (t >= 1.0f) cl = falls ? 0 : 2;                                           // :52 / :64
+    if (t < 0.0f) cl = falls ? 2 : 0;
+    if (!lin && delta < 0.0f) cl = (r.a > 0.0f) ? 0 : 2;                         // :59
+    return cl;
+}
+
+// As build_record, but the bracket is this cell's exact sample-row range, written as integers
+// into the lo / hi slots of the record (ra, re).  An empty range is ra = 1, re = 0.
+__device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t root, const RowGeom &G, Rec &r)
+{
+    const float p0x = (float)p[0], p0y = (float)p[1];
+    const float p1x = (float)p[2], p1y = (float)p[3];
+    const float p2x = (float)p[4], p2y = (float)p[5];
+    const float a = p0y - 2 * p1y + p2y;                 // :48
+    r.ax = p0x - 2 * p1x + p2x;                          // :53/:65
+    r.bx = 2 * (p1x - p0x);
+    r.p0x = p0x;
+    r.pad1 = 0;
+    const bool lin = a == 0.0f;                          // :49
+    const float b = p0y - p1y;
+    // ends of the accepted set in exact arithmetic: `start` is where t = 0 (or the vertex), `stop`
+    // where t = 1 (or the vertex); the vertex and t = 0 are accepted, t = 1 is not
+    bool empty;
+    float c_start = p0y, c_stop = p2y;
+    bool stop_incl = false;
+    if (lin) {
+        empty = (root != 0u) || (p2y == p0y);            // :50
+        r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
+        r.rden = 1.0f / r.c1;
+        r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
+    } else {
+        r.a = a; r.b = b; r.c1 = p1y * p1y; r.c2 = p0y * p2y;        // :58, :60
+        r.rden = 1.0f / a;
+        r.flags = root ? REC_NEG_ROOT : 0u;
+        const bool far_side = (root == 0u) == (a > 0.0f);            // this root satisfies (t - t_v) * 1 >= 0
+        const bool tv_le0 = (b * a) <= 0.0f, tv_lt0 = (b * a) < 0.0f;     // a, b are integers: signs are exact
+        const bool tv_ge1 = (a > 0.0f) ? (b >= a) : (b <= a);
+        const float yv = p0y - (b * b) / a;              // vertex height (a guess only)
+        if (far_side) {
+            empty = tv_ge1;
+            if (!tv_le0) c_start = yv;
+        } else {
+            empty = tv_lt0;
+            if (!tv_ge1) { c_stop = yv; stop_incl = true; }
+        }
+    }
+    uint32_t ra = 1u, re = 0u;
+    if (!empty) {
+        // guesses: first row at / strictly below an end
+        const float top = (float)G.rows;
+        const bool start_hi = c_start >= c_stop;
+        const float xh = G.row_of(start_hi ? c_start : c_stop), xl = G.row_of(start_hi ? c_stop : c_start);
+        const bool hi_incl = start_hi ? true : stop_incl, lo_incl = start_hi ? stop_incl : true;
+        const float fa = hi_incl ? __builtin_ceilf(xh) : __builtin_floorf(xh) + 1.0f;    // first row accepted
+        const float fe = lo_incl ? __builtin_floorf(xl) + 1.0f : __builtin_ceilf(xl);    // first row past it
+        ra = (uint32_t)fminf(fmaxf(fa, 0.0f), top);
+        re = (uint32_t)fminf(fmaxf(fe, 0.0f), top);
+        while (ra > 0u && classify_row(r, G.cy(ra - 1u)) <= 1) --ra;
+        while (ra < G.rows && classify_row(r, G.cy(ra)) == 2) ++ra;
+        if (re < ra) re = ra;
+        while (re > ra && classify_row(r, G.cy(re - 1u)) == 0) --re;
+        while (re < G.rows && classify_row(r, G.cy(re)) >= 1) ++re;
+    }
+    r.lo = __builtin_bit_cast(float, ra);
+    r.hi = __builtin_bit_cast(float, re);
+}
+
 }  // namespace fr

@@ -237,11 +237,18 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         const uint32_t s0g = A.glyph_seg_start[g];
         if (tid < rec_cnt) {
             Rec r;
+#if FR_WALK == 2
+            RowGeom geo;
+            geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+            build_record_rows(A.pts + 2u * (size_t)A.seg_p0[s0g + (tid >> 1)], tid & 1u, geo, r);
+            s_rec[tid] = r;
+#else
             if (!build_record(A.pts + 2u * (size_t)A.seg_p0[s0g + (tid >> 1)], tid & 1u, r)) {
                 r.lo = __builtin_inff(); r.hi = -__builtin_inff();
                 r.a = 1.f; r.b = 0.f; r.c1 = 0.f; r.c2 = 0.f; r.ax = 0.f; r.bx = 0.f; r.p0x = 0.f; r.flags = 0; r.rden = 1.f; r.pad1 = 0;
             }
             s_rec[tid] = stage(r);
+#endif
         }
     } else {
         // stage the first (usually only) 256-record chunk: one record per lane, issued first so
