@@ -240,10 +240,15 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
         const float fe = lo_incl ? __builtin_floorf(xl) + 1.0f : __builtin_ceilf(xl);    // first row past it
         ra = (uint32_t)fminf(fmaxf(fa, 0.0f), top);
         re = (uint32_t)fminf(fmaxf(fe, 0.0f), top);
+        // (one trip each when the guess is right: keep the compiler from unrolling them)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         while (ra > 0u && classify_row(r, G.cy(ra - 1u)) <= 1) --ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         while (ra < G.rows && classify_row(r, G.cy(ra)) == 2) ++ra;
         if (re < ra) re = ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         while (re > ra && classify_row(r, G.cy(re - 1u)) == 0) --re;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         while (re < G.rows && classify_row(r, G.cy(re)) >= 1) ++re;
     }
     r.lo = __builtin_bit_cast(float, ra);

@@ -82,8 +82,10 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x)
 #ifndef FR_WALK
 #define FR_WALK 2
 #endif
-// One crossing = 16 bits: (J << 1) | (sign > 0), J <= 2048 sample columns; 0xffff = no crossing.
-constexpr uint32_t EMPTY = 0xffffu;
+// One crossing = 16 bits: (J << 2) | code, J <= 1024 sample columns of a strip, winding step = code - 1
+// (code 2: +1, code 0: -1).  An unused slot is 0xfffd: it sorts last and its step is 0, so the
+// suffix sums and the toggle test need no "is this slot used" case.
+constexpr uint32_t EMPTY = 0xfffdu;
 constexpr uint32_t PCAP = 1024u;               // (record,row) pairs buffered per wave before a dense evaluation round
 constexpr uint32_t LSTRIDE = 40u;              // u16 slots per row list: 32 used + pad; an 80-byte
                                                // row stride makes one-row-per-lane b128 reads conflict-free
@@ -219,9 +221,13 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
             const float ge = ((float)job.max_y - r.lo * job.scale) * (float)N - ph;
             ra = (uint32_t)fminf(fmaxf(ga, 0.0f), top);
             re = (uint32_t)fminf(fmaxf(ge, 0.0f), top);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             while (ra > 0u && cy_of(ra - 1u) <= r.hi) --ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             while (ra < Hs && cy_of(ra) > r.hi) ++ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             while (re > 0u && cy_of(re - 1u) < r.lo) --re;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             while (re < Hs && cy_of(re) >= r.lo) ++re;
         }
         r.lo = __builtin_bit_cast(float, ra);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     uint16_t *mylist = s_lists + lane * LSTRIDE;
     {
         uint4 *f = reinterpret_cast<uint4 *>(mylist);
-        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        const uint4 ones = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
 #pragma unroll
         for (uint32_t q = 0; q < CAP / 8u; ++q) f[q] = ones;       // all EMPTY
     }
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
                 const float xx = (r.ax * t + r.bx) * t + r.p0x;
                 const float dy = r.a * t + (-r.b);
-                const int sgn = lin ? ((r.flags & REC_LIN_MINUS) ? -1 : 1) : ((dy > 0.0f) ? -1 : 1);
+                const bool minus = lin ? ((r.flags & REC_LIN_MINUS) != 0) : (dy > 0.0f);       // :55 / :68
                 // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
                 // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
                 // map, confirm with one paired read, walk only if the guess is off
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 if (accepted && J > 0) {
 #endif
                     const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
-                    if (pos < (uint32_t)CAP) s_lists[row * LSTRIDE + pos] = (uint16_t)(((uint32_t)J << 1) | (sgn > 0 ? 1u : 0u));
+                    if (pos < (uint32_t)CAP) s_lists[row * LSTRIDE + pos] = (uint16_t)(((uint32_t)J << 2) | (minus ? 0u : 2u));
                 }
             }
         }
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         const uint4 *f = reinterpret_cast<const uint4 *>(mylist);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 v = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            uint4 v = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
             if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = f[q];
             e[8 * q + 0] = v.x & 0xffffu; e[8 * q + 1] = v.x >> 16; e[8 * q + 2] = v.y & 0xffffu; e[8 * q + 3] = v.y >> 16;
             e[8 * q + 4] = v.z & 0xffffu; e[8 * q + 5] = v.z >> 16; e[8 * q + 6] = v.w & 0xffffu; e[8 * q + 7] = v.w >> 16;
@@ -516,6 +522,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) sort_network<12>(e);
         else sort_network<8>(e);
     }
+    // slots in use in the wave's fullest row: the toggle loop visits no more
+    const uint32_t maxcnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(min(cnt, (uint32_t)CAP)), 63);
     wave_lds_sync();                            // the list region becomes the mask region below
     STAMP(3);                                   // list pull + sort
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
@@ -548,28 +556,26 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #else
             if (mine_half) {
 #endif
-                unsigned long long *line = s_mask + ((size_t)mask_line(hrow) << nwin_log);
+                unsigned long long *line = s_mask + (mask_line(hrow) << nwin_log);
                 uint32_t fill = 0;
-                if (!ovf) {
-                    int run = 0;
+                // right to left: `run` = winding right of the slots handled so far; a slot toggles
+                // inside/outside iff the winding changes between zero and non-zero across it.
+                // Unused slots step by 0; an over-full row (redone by fixup_kernel) never reaches 0.
+                int run = ovf ? 0x40000000 : 0;
+                bool zero = !ovf;
 #pragma unroll
-                    for (int ch = 3; ch >= 0; --ch) {
-                        if (__ballot(e[ch * 8] != EMPTY) == 0ull) continue;     // sorted: chunk empty in every lane
-#pragma unroll
-                        for (int i = ch * 8 + 7; i >= ch * 8; --i) {
-                            if (e[i] != EMPTY) {
-                                const int before = run;
-                                run += (e[i] & 1u) ? 1 : -1;
-                                if ((run != 0) != (before != 0)) {
-                                    const uint32_t t = e[i] >> 1;                   // 1 .. ncol
-                                    const uint32_t wv = (t - 1u) >> WSHIFT;
-                                    const uint32_t cb = t - (wv << WSHIFT);         // 1 .. WCOLS bits set
-                                    atomicXor(line + wv, ~0ull >> (64u - cb));
-                                    fill ^= (1u << wv) - 1u;                        // every window to the left flips
-                                }
-                            }
-                        }
+                for (int i = CAP - 1; i >= 0; --i) {
+                    if (i >= (int)maxcnt) continue;                             // wave-uniform
+                    run += (int)(e[i] & 3u) - 1;
+                    const bool z = run == 0;
+                    if (z != zero) {
+                        const uint32_t tm1 = (e[i] >> 2) - 1u;                  // toggle column - 1, 0 .. ncol-1
+                        const uint32_t wv = tm1 >> WSHIFT;
+                        // columns [0, t) of the window: (tm1 mod WCOLS) + 1 low bits
+                        atomicXor(line + wv, ~0ull >> (63u - (tm1 & (uint32_t)(WCOLS - 1))));
+                        fill ^= (1u << wv) - 1u;                                // every window to the left flips
                     }
+                    zero = z;
                 }
                 s_fill[hrow] = fill;
             }
@@ -590,35 +596,35 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #pragma unroll
                     for (int rr = 0; rr < N; ++rr) {
                         const uint32_t r = yl * N + rr;
-                        const unsigned long long mk = s_mask[((size_t)mask_line(r) << nwin_log) + wx];
-                        mask[rr] = mk ^ (((s_fill[r] >> wx) & 1u) ? WALL : 0ull);
+                        const unsigned long long mk = s_mask[(mask_line(r) << nwin_log) + wx];
+                        // "windows left of a toggle are filled" parity of this window: 0 or all ones
+                        const uint32_t fl = (uint32_t)__builtin_amdgcn_sbfe((int)s_fill[r], wx, 1u);
+                        mask[rr] = mk ^ (((unsigned long long)(fl & (uint32_t)(WALL >> 32)) << 32) | (fl & (uint32_t)WALL));
                     }
                     uint32_t pk[4];
                     if (N == 4) {
-                        // SWAR: per-nibble popcounts of the 4 sample rows, summed per pixel
-                        unsigned long long s01 = 0, s23 = 0;
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            unsigned long long x = mask[rr];
-                            x = x - ((x >> 1) & 0x5555555555555555ull);
-                            x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
-                            if (rr < 2) s01 += x; else s23 += x;
-                        }
-                        const unsigned long long M = 0x0f0f0f0f0f0f0f0full;
-                        const unsigned long long ke = (s01 & M) + (s23 & M);                 // even pixels, 0..16
-                        const unsigned long long ko = ((s01 >> 4) & M) + ((s23 >> 4) & M);   // odd pixels
-                        // round_half_up(255*k/16) = 16k - (k > 8), per byte, in independent 32-bit halves
-                        uint32_t ve[2], vo[2];
+                        // SWAR per 32-bit half (8 pixels x 4 sample columns), the two halves never
+                        // exchange bits: pair counts, then the even / odd pairs of every nibble summed
+                        // over the 4 sample rows (<= 8 each), then even / odd pixels as bytes (<= 16)
 #pragma unroll
                         for (int hlf = 0; hlf < 2; ++hlf) {
-                            const uint32_t a = (uint32_t)(ke >> (32 * hlf)), b2 = (uint32_t)(ko >> (32 * hlf));
-                            ve[hlf] = (a << 4) - (((a + 0x07070707u) >> 4) & 0x01010101u);
-                            vo[hlf] = (b2 << 4) - (((b2 + 0x07070707u) >> 4) & 0x01010101u);
+                            uint32_t pa = 0, pb = 0;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                uint32_t x = (uint32_t)(mask[rr] >> (32 * hlf));
+                                x = x - ((x >> 1) & 0x55555555u);
+                                pa += x & 0x33333333u;
+                                pb += (x >> 2) & 0x33333333u;
+                            }
+                            const uint32_t M = 0x0f0f0f0fu;
+                            const uint32_t ke = (pa & M) + (pb & M);                    // even pixels, 0..16
+                            const uint32_t ko = ((pa >> 4) & M) + ((pb >> 4) & M);      // odd pixels
+                            // round_half_up(255*k/16) = 16k - (k > 8), per byte
+                            const uint32_t ve = (ke << 4) - (((ke + 0x07070707u) >> 4) & 0x01010101u);
+                            const uint32_t vo = (ko << 4) - (((ko + 0x07070707u) >> 4) & 0x01010101u);
+                            pk[2 * hlf + 0] = __builtin_amdgcn_perm(vo, ve, 0x05010400u);
+                            pk[2 * hlf + 1] = __builtin_amdgcn_perm(vo, ve, 0x07030602u);
                         }
-                        pk[0] = __builtin_amdgcn_perm(vo[0], ve[0], 0x05010400u);
-                        pk[1] = __builtin_amdgcn_perm(vo[0], ve[0], 0x07030602u);
-                        pk[2] = __builtin_amdgcn_perm(vo[1], ve[1], 0x05010400u);
-                        pk[3] = __builtin_amdgcn_perm(vo[1], ve[1], 0x07030602u);
                     } else {
                         pk[0] = pk[1] = pk[2] = pk[3] = 0;
 #pragma unroll
@@ -655,8 +661,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 #pragma unroll
                 for (int i = CAP - 1; i >= 0; --i) {
                     const bool have = e[i] != EMPTY;
-                    if (have) run += (e[i] & 1u) ? 1 : -1;
-                    dst[i] = have ? (((e[i] >> 1) << 16) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
+                    run += (int)(e[i] & 3u) - 1;
+                    dst[i] = have ? (((e[i] >> 2) << 16) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
                 }
                 if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
             }
