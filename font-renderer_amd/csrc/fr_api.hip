@@ -18,6 +18,7 @@ namespace fr {
 void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *, uint32_t *,
                     hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
+uint32_t render_wg_waves();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
                        uint8_t *, hipStream_t);
@@ -410,8 +411,9 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     // one workgroup walks all bands of its cell (cx table, job and records staged once)
     // unless the batch is too small to fill the chip: then split the bands over workgroups
     // (bands are wave bands of 64/n pixel rows; a workgroup's 4 waves take them round-robin)
-    uint32_t bpw = (plan->bands + 3u) & ~3u;
-    while (bpw > 4 && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + 3u) & ~3u;
+    const uint32_t nw = fr::render_wg_waves();
+    uint32_t bpw = (plan->bands + nw - 1u) / nw * nw;
+    while (bpw > nw && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + nw - 1u) / nw * nw;
     a.bands_per_wg = bpw;
     a.band_groups = (plan->bands + bpw - 1) / bpw;
     a.ovf_bits = plan->d_ovf_bits;

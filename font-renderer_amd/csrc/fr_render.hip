@@ -110,6 +110,11 @@ __device__ __forceinline__ void sort_network(uint32_t (&e)[32])
 }
 // records staged in LDS per pass
 constexpr uint32_t RCHUNK = 256u;
+// waves per workgroup: they share one cell's records and cx table and take its wave bands round-robin
+#ifndef FR_WG_WAVES
+#define FR_WG_WAVES 4
+#endif
+constexpr uint32_t NW = FR_WG_WAVES;
 // Diagnostic build only (make STAMPS=1 -> libfr_raster_stamps.so): per-phase shader-clock
 // sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
 // library is built without FR_STAMPS and executes no stamp.
@@ -159,7 +164,12 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 template <int MODE, int N, int CAP>
-__global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
+#ifdef FR_WAVES_PER_EU
+#define FR_OCC __attribute__((amdgpu_waves_per_eu(FR_WAVES_PER_EU, FR_WAVES_PER_EU)))
+#else
+#define FR_OCC
+#endif
+__global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const RenderArgs A)
 {
     constexpr uint32_t WBAND = 64u / N;         // pixel rows per wave band (64 sample rows)
     constexpr uint32_t PARTS = FR_BAND_PARTS;   // 1: whole band at once (8 KB of masks per wave); 2: two half bands (4 KB)
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
     auto col_cx = [&](uint32_t j) -> float {
         return ((float)(min_xs + (int32_t)(j / N)) + sub_off((int)(j % N), N, phase)) / job.scale;
     };
-    for (uint32_t j = tid; j < ncol; j += 256u) s_cxp[1u + j] = col_cx(j);
+    for (uint32_t j = tid; j < ncol; j += 64u * NW) s_cxp[1u + j] = col_cx(j);
     if (tid == 2) s_cxp[0] = -__builtin_inff();
     if (tid == 3) s_cxp[1u + ncol] = __builtin_inff();
 
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 
   // wave w takes wave bands band_first + w, + 4, ...; every wave runs the same trip count so the
   // (rare) multi-chunk restaging barriers line up
-  for (uint32_t band0 = band_first; band0 < band_end; band0 += 4u) {
+  for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
     const uint32_t band = band0 + wave;
     const bool band_valid = band < band_end;
     const uint32_t y0 = band * WBAND;
@@ -802,10 +812,10 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     const size_t walk = 64u * LSTRIDE * 2u + PCAP * 2u + 64u * 8u + RCHUNK * 2u;   // lists, pairs / markers, cy, counters, run offsets
     if (wb < walk) wb = walk;                                  // the walk's buffers live here first
     const size_t rb = (size_t)RCHUNK * sizeof(Rec);
-    const size_t t = cx + rb + 4 * wb;
+    const size_t t = cx + rb + NW * wb;
     *rec_bytes = (uint32_t)rb;
     *nwin_log = lg; *region = (uint32_t)cx; *wave_bytes = (uint32_t)wb; *tail = (uint32_t)t;
-    *total = t + 4 * prow * 4;
+    *total = t + NW * prow * 4;
 }
 
 template <int MODE, int N, int CAP>
@@ -820,7 +830,7 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t nwords = (size_t)a.n_jobs * a.bands * a.strips;
@@ -836,6 +846,8 @@ static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
     if (a.kmax <= 16) return launch_one<MODE, N, 16>(a, grid, stream);
     return launch_one<MODE, N, 32>(a, grid, stream);
 }
+
+uint32_t render_wg_waves() { return NW; }
 
 hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t stream)
 {
