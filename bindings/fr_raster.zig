@@ -62,6 +62,9 @@ pub extern "c" fn fr_render_glyph(ctx: *fr_ctx, points_xy: [*]const i16, contour
 pub extern "c" fn fr_glyph_info_init(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, curve_type: [*]u8, include_p0: [*]u8) c_int;
 pub extern "c" fn fr_winding_in_glyph(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, query_xy: [*]const i16, n_query: u32, out_winding: [*]i16) c_int;
 pub extern "c" fn fr_winding_lattice(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, box: *const [4]i16, out_host: [*]i16) c_int;
+// build-defined (no reference counterpart): the exact-integer path on a K-times refined lattice
+pub extern "c" fn fr_exact_lattice(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, k: u32, x0: i32, y0: i32, w: u32, h: u32, out_host: [*]i16) c_int;
+pub extern "c" fn fr_exact_coverage(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, k: u32, x0: i32, y0: i32, w_px: u32, h_px: u32, n: u32, out_host: [*]u8) c_int;
 
 pub const Error = error{ RasterFailed, OutOfMemory };
 

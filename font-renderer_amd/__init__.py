@@ -14,6 +14,6 @@ from ._lib import (  # noqa: F401
 )
 from .render_glyph import (  # noqa: F401
     Context, GlyphInfo, Plan, DeviceGlyphSet, renderGlyph, render_glyph_dims, windingInGlyph,
-    winding_lattice,
+    winding_lattice, exact_lattice, exact_coverage,
 )
 from .font import Font  # noqa: F401

@@ -60,6 +60,8 @@ SYMBOLS = [
     ("fr_glyph_info_init", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("fr_winding_in_glyph", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     ("fr_winding_lattice", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    ("fr_exact_lattice", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, _P]),
+    ("fr_exact_coverage", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("fr_font_open", C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),
     ("fr_font_close", None, [_P]),
     ("fr_font_info", C.c_int, [_P, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int)]),

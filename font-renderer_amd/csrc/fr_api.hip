@@ -20,11 +20,12 @@ void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 uint32_t render_wg_waves();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
-void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, uint8_t *,
+void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, int, uint8_t *,
                        uint8_t *, hipStream_t);
 void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
-                          uint32_t, const int16_t *, uint64_t, uint32_t, int, int, int16_t *,
+                          uint32_t, const int16_t *, uint64_t, uint32_t, int, int, int, int16_t *,
                           hipStream_t);
+void launch_exact_cover(const int16_t *, uint32_t, uint32_t, uint32_t, uint8_t *, hipStream_t);
 }  // namespace fr
 
 static_assert(sizeof(fr_job) == sizeof(fr::Job), "fr_job layout");
@@ -532,11 +533,12 @@ struct ExactDev {
     uint32_t *seg_p0 = nullptr, *seg_prev = nullptr;
     uint8_t *ctype = nullptr, *inc = nullptr;
     uint32_t n_seg = 0;
+    int K = 1;
     ~ExactDev() { dfree(pts); dfree(seg_p0); dfree(seg_prev); dfree(ctype); dfree(inc); }
 };
 
 static int exact_setup(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
-                       uint32_t n_contours, ExactDev &d)
+                       uint32_t n_contours, ExactDev &d, int K = 1)
 {
     if (!ctx) return fail(FR_E_INVALID, "ctx is NULL");
     std::vector<uint32_t> seg_p0, seg_prev;
@@ -557,7 +559,8 @@ static int exact_setup(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
         HIP_TRY(hipMemcpyAsync(d.seg_p0, seg_p0.data(), (size_t)d.n_seg * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(d.seg_prev, seg_prev.data(), (size_t)d.n_seg * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    fr::launch_glyph_info(d.pts, d.seg_p0, d.seg_prev, d.n_seg, d.ctype, d.inc, ctx->stream);
+    d.K = K;
+    fr::launch_glyph_info(d.pts, d.seg_p0, d.seg_prev, d.n_seg, K, d.ctype, d.inc, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FR_OK;
@@ -577,8 +580,11 @@ int fr_glyph_info_init(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     return FR_OK;
 }
 
+// cover_n > 0: the lattice is (cover_w * cover_n) x (cover_h * cover_n) points and out_host receives
+// cover_w x cover_h u8 coverage values instead of the windings
 static int exact_run(fr_ctx *ctx, ExactDev &d, const int16_t *query_xy, uint64_t n_query,
-                     uint32_t lat_w, int x_min, int y_max, int16_t *out_host)
+                     uint32_t lat_w, int lat_x0, int lat_y0, void *out_host,
+                     uint32_t cover_w = 0, uint32_t cover_h = 0, uint32_t cover_n = 0)
 {
     if (n_query == 0) return FR_OK;
     if (!out_host) return fail(FR_E_INVALID, "output is NULL");
@@ -588,13 +594,24 @@ static int exact_run(fr_ctx *ctx, ExactDev &d, const int16_t *query_xy, uint64_t
     if (e == hipSuccess && query_xy) e = hipMalloc(&d_q, n_query * 4);
     if (e == hipSuccess && query_xy) e = hipMemcpyAsync(d_q, query_xy, n_query * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        fr::launch_exact_winding(d.pts, d.seg_p0, d.ctype, d.inc, d.n_seg, d_q, n_query, lat_w, x_min, y_max, d_out, ctx->stream);
+        fr::launch_exact_winding(d.pts, d.seg_p0, d.ctype, d.inc, d.n_seg, d_q, n_query, lat_w, lat_x0, lat_y0, d.K, d_out, ctx->stream);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, n_query * 2, hipMemcpyDeviceToHost, ctx->stream);
+    uint8_t *d_cov = nullptr;
+    if (cover_n) {
+        const size_t npx = (size_t)cover_w * cover_h;
+        if (e == hipSuccess) e = hipMalloc(&d_cov, npx ? npx : 1);
+        if (e == hipSuccess) {
+            fr::launch_exact_cover(d_out, cover_w, cover_h, cover_n, d_cov, ctx->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_cov, npx, hipMemcpyDeviceToHost, ctx->stream);
+    } else if (e == hipSuccess) {
+        e = hipMemcpyAsync(out_host, d_out, n_query * 2, hipMemcpyDeviceToHost, ctx->stream);
+    }
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = e2;
-    dfree(d_q); dfree(d_out);
+    dfree(d_q); dfree(d_out); dfree(d_cov);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "exact winding: %s", hipGetErrorString(e));
     return FR_OK;
 }
@@ -619,7 +636,43 @@ int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     ExactDev d;
     int rc = exact_setup(ctx, points_xy, contour_start, n_contours, d);
     if (rc) return rc;
-    return exact_run(ctx, d, nullptr, (uint64_t)W * H, (uint32_t)W, box[0], box[3], out_host);
+    return exact_run(ctx, d, nullptr, (uint64_t)W * H, (uint32_t)W, box[0] - 1, box[3] + 1, out_host);
+}
+
+// 128-bit predicates hold dy*abxy^2 < 2^106 * K^6 for i16 points scaled by K: K <= 8 cannot overflow
+static int check_k(uint32_t K, int32_t x0, int32_t y0, uint64_t w, uint64_t h)
+{
+    if (K < 1 || K > 8) return fail(FR_E_UNSUPPORTED, "K must be in [1, 8] (128-bit predicate range)");
+    if (w > (1u << 20) || h > (1u << 20)) return fail(FR_E_UNSUPPORTED, "lattice larger than 2^20 per axis");
+    const int64_t lim = (int64_t)1 << 20;           // query points stay within a few em of the scaled glyph
+    if (x0 < -lim || x0 + (int64_t)w > lim || y0 > lim || y0 - (int64_t)h < -lim)
+        return fail(FR_E_UNSUPPORTED, "lattice beyond +-2^20 scaled units");
+    return FR_OK;
+}
+
+int fr_exact_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                     uint32_t n_contours, uint32_t K, int32_t x0, int32_t y0, uint32_t w, uint32_t h,
+                     int16_t *out_host)
+{
+    int rc = check_k(K, x0, y0, w, h);
+    if (rc) return rc;
+    ExactDev d;
+    rc = exact_setup(ctx, points_xy, contour_start, n_contours, d, (int)K);
+    if (rc) return rc;
+    return exact_run(ctx, d, nullptr, (uint64_t)w * h, w, x0, y0, out_host);
+}
+
+int fr_exact_coverage(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                      uint32_t n_contours, uint32_t K, int32_t x0, int32_t y0, uint32_t w_px, uint32_t h_px,
+                      uint32_t n, uint8_t *out_host)
+{
+    if (n < 1 || n > 8) return fail(FR_E_INVALID, "samples per axis must be in [1, 8]");
+    int rc = check_k(K, x0, y0, (uint64_t)w_px * n, (uint64_t)h_px * n);
+    if (rc) return rc;
+    ExactDev d;
+    rc = exact_setup(ctx, points_xy, contour_start, n_contours, d, (int)K);
+    if (rc) return rc;
+    return exact_run(ctx, d, nullptr, (uint64_t)w_px * n * h_px * n, w_px * n, x0, y0, out_host, w_px, h_px, n);
 }
 
 }  // extern "C"

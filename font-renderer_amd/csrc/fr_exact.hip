@@ -41,15 +41,16 @@ __device__ inline uint8_t curve_type(int p0x, int p0y, int p1x, int p1y, int p2x
 __global__ __launch_bounds__(256) void glyph_info_kernel(const int16_t *__restrict__ pts,
                                                          const uint32_t *__restrict__ seg_p0,
                                                          const uint32_t *__restrict__ seg_prev,
-                                                         uint32_t n_seg, uint8_t *__restrict__ ctype,
+                                                         uint32_t n_seg, int K, uint8_t *__restrict__ ctype,
                                                          uint8_t *__restrict__ inc_p0)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= n_seg) return;
     const int16_t *p = pts + 2u * (size_t)seg_p0[s];
     const int16_t *q = pts + 2u * (size_t)seg_prev[s];
-    const int p_2y = q[1], p_1y = q[3];
-    const int p0x = p[0], p0y = p[1], p1x = p[2], p1y = p[3], p2x = p[4], p2y = p[5];
+    // K > 1: the same rules applied to the glyph scaled by K
+    const int p_2y = K * q[1], p_1y = K * q[3];
+    const int p0x = K * p[0], p0y = K * p[1], p1x = K * p[2], p1y = K * p[3], p2x = K * p[4], p2y = K * p[5];
     const int prev_end = 2 * isign_(p0y - p_1y) + isign_(p0y - p_2y);          // :132
     const int curr_start = 2 * isign_(p1y - p0y) + isign_(p2y - p0y);          // :133
     inc_p0[s] = (uint8_t)(curr_start != 0 && (prev_end == 0 || ((prev_end > 0) != (curr_start < 0))));   // :136
@@ -99,10 +100,11 @@ __device__ inline bool solve1(Pt p, Pt p0, Pt p1, Pt p2, bool tilt_up)          
     return dy * abxy * abxy <= tmp * tmp;
 }
 
-struct CurveLds {   // 16 B
-    int16_t p0x, p0y, p1x, p1y, p2x, p2y;
+struct CurveLds {   // 32 B (coordinates of the K-times scaled glyph: up to 2^18)
+    int32_t p0x, p0y, p1x, p1y, p2x, p2y;
     uint8_t type, inc;
     uint16_t pad;
+    uint32_t pad2;
 };
 
 __device__ inline int curve_winding(const CurveLds &c, Pt p)                    // :170-243
@@ -186,8 +188,11 @@ __device__ inline int curve_winding(const CurveLds &c, Pt p)                    
     return w;
 }
 
-// queries == nullptr: lattice of Image.GlyphDebug.render (Image.zig:227-236), query q ->
-// (w, h) = (q % lat_w, q / lat_w), point (x_min + w - 1, y_max - h + 1).
+// queries == nullptr: a lattice, query q -> (w, h) = (q % lat_w, q / lat_w), point
+// (lat_x0 + w, lat_y0 - h); Image.GlyphDebug.render (Image.zig:227-236) is lat_x0 = x_min - 1,
+// lat_y0 = y_max + 1.  The glyph's points are multiplied by K first (K = 1: the reference's own
+// path; K = 2..8: the K-times refined lattice of SURVEY §8 f-3, whose integer points are the
+// font-unit points (x / K, y / K)).
 __global__ __launch_bounds__(256) void exact_winding_kernel(const int16_t *__restrict__ pts,
                                                             const uint32_t *__restrict__ seg_p0,
                                                             const uint8_t *__restrict__ ctype,
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void exact_winding_kernel(const int16_t *__res
                                                             uint32_t n_seg,
                                                             const int16_t *__restrict__ queries,
                                                             uint64_t n_query, uint32_t lat_w,
-                                                            int x_min, int y_max,
+                                                            int lat_x0, int lat_y0, int K,
                                                             int16_t *__restrict__ out)
 {
     __shared__ CurveLds s_curve[256];
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256) void exact_winding_kernel(const int16_t *__res
     Pt p{0, 0};
     if (valid) {
         if (queries) { p.x = queries[2 * q]; p.y = queries[2 * q + 1]; }
-        else { p.x = x_min + (int)(q % lat_w) - 1; p.y = y_max - (int)(q / lat_w) + 1; }
+        else { p.x = lat_x0 + (int)(q % lat_w); p.y = lat_y0 - (int)(q / lat_w); }
     }
     int w = 0;
     for (uint32_t base = 0; base < n_seg; base += 256u) {
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256) void exact_winding_kernel(const int16_t *__res
         if (s < n_seg) {
             const int16_t *pp = pts + 2u * (size_t)seg_p0[s];
             CurveLds c;
-            c.p0x = pp[0]; c.p0y = pp[1]; c.p1x = pp[2]; c.p1y = pp[3]; c.p2x = pp[4]; c.p2y = pp[5];
-            c.type = ctype[s]; c.inc = inc_p0[s]; c.pad = 0;
+            c.p0x = K * pp[0]; c.p0y = K * pp[1]; c.p1x = K * pp[2]; c.p1y = K * pp[3]; c.p2x = K * pp[4]; c.p2y = K * pp[5];
+            c.type = ctype[s]; c.inc = inc_p0[s]; c.pad = 0; c.pad2 = 0;
             s_curve[threadIdx.x] = c;
         }
         __syncthreads();
@@ -226,22 +231,44 @@ __global__ __launch_bounds__(256) void exact_winding_kernel(const int16_t *__res
 }
 
 void launch_glyph_info(const int16_t *pts, const uint32_t *seg_p0, const uint32_t *seg_prev,
-                       uint32_t n_seg, uint8_t *ctype, uint8_t *inc_p0, hipStream_t stream)
+                       uint32_t n_seg, int K, uint8_t *ctype, uint8_t *inc_p0, hipStream_t stream)
 {
     if (!n_seg) return;
     hipLaunchKernelGGL(glyph_info_kernel, dim3((n_seg + 255u) / 256u), dim3(256), 0, stream, pts,
-                       seg_p0, seg_prev, n_seg, ctype, inc_p0);
+                       seg_p0, seg_prev, n_seg, K, ctype, inc_p0);
+}
+
+// n x n lattice points per pixel -> round_half_up(255 * inside / n^2), inside = winding != 0
+// (the box-filtered non-zero fill of FR_COVERAGE_U8, on the exact-integer inside test)
+__global__ __launch_bounds__(256) void exact_cover_kernel(const int16_t *__restrict__ wind, uint32_t w_px,
+                                                          uint32_t h_px, uint32_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (q >= (uint64_t)w_px * h_px) return;
+    const uint32_t x = (uint32_t)(q % w_px), y = (uint32_t)(q / w_px);
+    uint32_t inside = 0;
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t i = 0; i < n; ++i)
+            inside += wind[((size_t)y * n + j) * ((size_t)w_px * n) + (size_t)x * n + i] != 0;
+    out[q] = (uint8_t)((2u * 255u * inside + n * n) / (2u * n * n));
+}
+
+void launch_exact_cover(const int16_t *wind, uint32_t w_px, uint32_t h_px, uint32_t n, uint8_t *out, hipStream_t stream)
+{
+    const uint64_t nq = (uint64_t)w_px * h_px;
+    if (!nq) return;
+    hipLaunchKernelGGL(exact_cover_kernel, dim3((uint32_t)((nq + 255u) / 256u)), dim3(256), 0, stream, wind, w_px, h_px, n, out);
 }
 
 void launch_exact_winding(const int16_t *pts, const uint32_t *seg_p0, const uint8_t *ctype,
                           const uint8_t *inc_p0, uint32_t n_seg, const int16_t *queries,
-                          uint64_t n_query, uint32_t lat_w, int x_min, int y_max, int16_t *out,
+                          uint64_t n_query, uint32_t lat_w, int lat_x0, int lat_y0, int K, int16_t *out,
                           hipStream_t stream)
 {
     if (!n_query) return;
     hipLaunchKernelGGL(exact_winding_kernel, dim3((uint32_t)((n_query + 255u) / 256u)), dim3(256), 0,
-                       stream, pts, seg_p0, ctype, inc_p0, n_seg, queries, n_query, lat_w, x_min,
-                       y_max, out);
+                       stream, pts, seg_p0, ctype, inc_p0, n_seg, queries, n_query, lat_w, lat_x0,
+                       lat_y0, K, out);
 }
 
 }  // namespace fr

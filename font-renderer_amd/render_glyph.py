@@ -237,3 +237,23 @@ def winding_lattice(glyph: Glyph, *, ctx: Optional[Context] = None) -> np.ndarra
     out = np.zeros((H, W), np.int16)
     L.check(ctx._lib.fr_winding_lattice(ctx._h, L.ptr(pts), L.ptr(cstart), nc, L.ptr(box), L.ptr(out)))
     return out
+
+
+def exact_lattice(glyph: Glyph, K: int, x0: int, y0: int, w: int, h: int, *, ctx: Optional[Context] = None) -> np.ndarray:
+    """SURVEY §8 f-3 (build-defined): GlyphInfo.init + windingInGlyph (render_glyph.zig:110-300) on the
+    glyph scaled by K, at the integer points (x0 + i, y0 - j) of the scaled glyph: (h, w) int16"""
+    ctx = ctx or default_context()
+    pts, cstart, nc = _flat(glyph)
+    out = np.zeros((h, w), np.int16)
+    L.check(ctx._lib.fr_exact_lattice(ctx._h, L.ptr(pts), L.ptr(cstart), nc, K, x0, y0, w, h, L.ptr(out)))
+    return out
+
+
+def exact_coverage(glyph: Glyph, K: int, x0: int, y0: int, w_px: int, h_px: int, n: int, *,
+                   ctx: Optional[Context] = None) -> np.ndarray:
+    """n x n lattice points per pixel of exact_lattice -> round_half_up(255 * inside / n^2): (h_px, w_px) u8"""
+    ctx = ctx or default_context()
+    pts, cstart, nc = _flat(glyph)
+    out = np.zeros((h_px, w_px), np.uint8)
+    L.check(ctx._lib.fr_exact_coverage(ctx._h, L.ptr(pts), L.ptr(cstart), nc, K, x0, y0, w_px, h_px, n, L.ptr(out)))
+    return out

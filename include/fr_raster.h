@@ -172,6 +172,23 @@ int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *c
 int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                        uint32_t n_contours, const int16_t box[4], int16_t *out_host);
 
+/* ---- exact-integer sampling on a K-times refined lattice (BUILD-DEFINED) ----
+ * GlyphInfo.init + windingInGlyph (render_glyph.zig:110-146, :160-300) applied, rule for rule, to
+ * the glyph whose points are multiplied by K (1 <= K <= 8, so the 128-bit predicates cannot
+ * overflow), at the integer points (x0 + i, y0 - j), i < w, j < h of that scaled glyph — i.e. at
+ * the font-unit points ((x0+i)/K, (y0-j)/K) with no floating point anywhere.  K = 1 is the
+ * reference's own lattice.  fr_exact_coverage evaluates n x n lattice points per pixel
+ * (lattice (w_px*n) x (h_px*n)) and writes round_half_up(255 * #{winding != 0} / n^2), the same
+ * box-filtered non-zero fill as FR_COVERAGE_U8 on the integer inside test.  The reference has no
+ * such mode (its exact path is dead code used only by GlyphDebug at K = 1); parity is against the
+ * oracle's twin of the same definition.                                                        */
+int fr_exact_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                     uint32_t n_contours, uint32_t K, int32_t x0, int32_t y0, uint32_t w, uint32_t h,
+                     int16_t *out_host /* [h][w] */);
+int fr_exact_coverage(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                      uint32_t n_contours, uint32_t K, int32_t x0, int32_t y0, uint32_t w_px, uint32_t h_px,
+                      uint32_t n, uint8_t *out_host /* [h_px][w_px] */);
+
 /* ---- contour producer (host side): TrueType glyf/loca -> Glyph contour layout ------------
  * What font/Font.zig + font/ttf.zig + font/Glyph.zig do in the reference (Font.initTTF :31,
  * loadGlyph :171, SimpleGlyph.initFromReader ttf.zig:759, ComponentGlyph ttf.zig:830,

@@ -377,9 +377,8 @@ int or_render_batch(const int16_t *pts, const uint32_t *cstart, const uint32_t *
 static int iabs(int v) { return v < 0 ? -v : v; }
 static int isign(int v) { return (v > 0) - (v < 0); }
 
-uint8_t or_curve_type(const int16_t p0[2], const int16_t p1[2], const int16_t p2[2])
+static uint8_t curve_type_i(int p0x, int p0y, int p1x, int p1y, int p2x, int p2y)
 {
-    int p0x = p0[0], p0y = p0[1], p1x = p1[0], p1y = p1[1], p2x = p2[0], p2y = p2[1];
     if (p0y == p2y) return (p1y == p0y) ? OR_X_AXIS : OR_BALANCE;                       /* :97 */
     if (p0y < p2y) {                                                                    /* :98 */
         if (iabs(p0x + p2x - 2 * p1x) <= 1 && iabs(p0y + p2y - 2 * p1y) <= 1) return OR_UP_STRIGHT; /* :99 */
@@ -392,8 +391,15 @@ uint8_t or_curve_type(const int16_t p0[2], const int16_t p1[2], const int16_t p2
     }
 }
 
-void or_glyph_info_init(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
-                        uint8_t *curve_type, uint8_t *include_p0)
+uint8_t or_curve_type(const int16_t p0[2], const int16_t p1[2], const int16_t p2[2])
+{
+    return curve_type_i(p0[0], p0[1], p1[0], p1[1], p2[0], p2[1]);
+}
+
+/* K = 1 is GlyphInfo.init; K > 1 applies the same rules to the glyph scaled by K (SURVEY §8 f-3,
+ * build-defined: the reference has no such mode) */
+static void glyph_info_init_k(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, int K,
+                              uint8_t *curve_type, uint8_t *include_p0)
 {
     size_t o = 0;
     for (uint32_t c = 0; c < n_contours; ++c) {                                         /* :123 */
@@ -406,14 +412,20 @@ void or_glyph_info_init(const int16_t *pts, const uint32_t *cstart, uint32_t n_c
             const int16_t *p0 = cp + 2 * (2 * k);
             const int16_t *p1 = cp + 2 * (2 * k + 1);
             const int16_t *p2 = cp + 2 * (2 * k + 2);
-            int prev_end = 2 * isign(p0[1] - p_1[1]) + isign(p0[1] - p_2[1]);           /* :132 */
-            int curr_start = 2 * isign(p1[1] - p0[1]) + isign(p2[1] - p0[1]);           /* :133 */
+            int prev_end = 2 * isign(K * p0[1] - K * p_1[1]) + isign(K * p0[1] - K * p_2[1]);   /* :132 */
+            int curr_start = 2 * isign(K * p1[1] - K * p0[1]) + isign(K * p2[1] - K * p0[1]);   /* :133 */
             include_p0[o] = (uint8_t)(curr_start != 0 &&
                 (prev_end == 0 || ((prev_end > 0) ^ (curr_start < 0))));                /* :136 */
-            curve_type[o] = or_curve_type(p0, p1, p2);                                  /* :137 */
+            curve_type[o] = curve_type_i(K * p0[0], K * p0[1], K * p1[0], K * p1[1], K * p2[0], K * p2[1]); /* :137 */
             ++o;
         }
     }
+}
+
+void or_glyph_info_init(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
+                        uint8_t *curve_type, uint8_t *include_p0)
+{
+    glyph_info_init_k(pts, cstart, n_contours, 1, curve_type, include_p0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -486,9 +498,9 @@ int or_solve1_root_crossing(const int32_t p[2], const int32_t p0[2], const int32
 /* ------------------------------------------------------------------------- */
 /* a5: windingInGlyph  (render_glyph.zig:160-247)                              */
 /* ------------------------------------------------------------------------- */
-int16_t or_winding_in_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
-                            const uint8_t *curve_type, const uint8_t *include_p0,
-                            int16_t px, int16_t py)
+static int16_t winding_in_glyph_k(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
+                                  const uint8_t *curve_type, const uint8_t *include_p0,
+                                  int K, int32_t px, int32_t py)
 {
     const int32_t p[2] = { px, py };                                           /* :161 */
     int16_t winding = 0;                                                       /* :163 */
@@ -497,9 +509,9 @@ int16_t or_winding_in_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t
         const int16_t *cp = pts + 2 * (size_t)cstart[c];
         uint32_t curve_count = (cstart[c + 1] - cstart[c]) / 2;
         for (uint32_t k = 0; k < curve_count; ++k, ++o) {                      /* :165 */
-            const int32_t p0[2] = { cp[2 * (2 * k)], cp[2 * (2 * k) + 1] };           /* :166 */
-            const int32_t p1[2] = { cp[2 * (2 * k + 1)], cp[2 * (2 * k + 1) + 1] };   /* :167 */
-            const int32_t p2[2] = { cp[2 * (2 * k + 2)], cp[2 * (2 * k + 2) + 1] };   /* :168 */
+            const int32_t p0[2] = { K * cp[2 * (2 * k)], K * cp[2 * (2 * k) + 1] };           /* :166 */
+            const int32_t p1[2] = { K * cp[2 * (2 * k + 1)], K * cp[2 * (2 * k + 1) + 1] };   /* :167 */
+            const int32_t p2[2] = { K * cp[2 * (2 * k + 2)], K * cp[2 * (2 * k + 2) + 1] };   /* :168 */
             const int inc = include_p0[o] != 0;
             switch (curve_type[o]) {                                           /* :170 */
             case OR_X_AXIS: break;                                             /* :171 */
@@ -579,6 +591,13 @@ int16_t or_winding_in_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t
     return winding;                                                            /* :246 */
 }
 
+int16_t or_winding_in_glyph(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
+                            const uint8_t *curve_type, const uint8_t *include_p0,
+                            int16_t px, int16_t py)
+{
+    return winding_in_glyph_k(pts, cstart, n_contours, curve_type, include_p0, 1, px, py);
+}
+
 static size_t total_curves(const uint32_t *cstart, uint32_t n_contours)
 {
     size_t n = 0;
@@ -601,6 +620,37 @@ void or_winding_lattice(const int16_t *pts, const uint32_t *cstart, uint32_t n_c
             out[(size_t)h * W + w] = or_winding_in_glyph(pts, cstart, n_contours, ct, ip, x, y);
         }
     free(ct); free(ip);
+}
+
+/* SURVEY §8 f-3 (BUILD-DEFINED twin of fr_exact_lattice / fr_exact_coverage): a4-a7 applied to the
+ * glyph scaled by K, at the integer points (x0 + i, y0 - j) of the scaled glyph */
+void or_exact_lattice(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, uint32_t K,
+                      int32_t x0, int32_t y0, uint32_t w, uint32_t h, int16_t *out)
+{
+    size_t nc = total_curves(cstart, n_contours);
+    uint8_t *ct = (uint8_t *)malloc(nc ? nc : 1), *ip = (uint8_t *)malloc(nc ? nc : 1);
+    glyph_info_init_k(pts, cstart, n_contours, (int)K, ct, ip);
+    for (uint32_t j = 0; j < h; ++j)
+        for (uint32_t i = 0; i < w; ++i)
+            out[(size_t)j * w + i] = winding_in_glyph_k(pts, cstart, n_contours, ct, ip, (int)K,
+                                                        x0 + (int32_t)i, y0 - (int32_t)j);
+    free(ct); free(ip);
+}
+
+void or_exact_coverage(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, uint32_t K,
+                       int32_t x0, int32_t y0, uint32_t w_px, uint32_t h_px, uint32_t n, uint8_t *out)
+{
+    size_t W = (size_t)w_px * n, H = (size_t)h_px * n;
+    int16_t *lat = (int16_t *)malloc((W * H ? W * H : 1) * sizeof(int16_t));
+    or_exact_lattice(pts, cstart, n_contours, K, x0, y0, (uint32_t)W, (uint32_t)H, lat);
+    for (uint32_t y = 0; y < h_px; ++y)
+        for (uint32_t x = 0; x < w_px; ++x) {
+            uint32_t inside = 0;
+            for (uint32_t j = 0; j < n; ++j)
+                for (uint32_t i = 0; i < n; ++i) inside += lat[((size_t)y * n + j) * W + (size_t)x * n + i] != 0;
+            out[(size_t)y * w_px + x] = (uint8_t)((2u * 255u * inside + n * n) / (2u * n * n));
+        }
+    free(lat);
 }
 
 /* ------------------------------------------------------------------------- */

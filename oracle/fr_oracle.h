@@ -120,6 +120,11 @@ void or_diag_reset(void);
  * out is (x_max-x_min+3) x (y_max-y_min+3) int16 windings, point (x_min+w-1, y_max-h+1) */
 void or_winding_lattice(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours,
                         const int16_t box[4], int16_t *out);
+/* SURVEY §8 f-3, build-defined: a4-a7 on the glyph scaled by K at the integer points (x0+i, y0-j) */
+void or_exact_lattice(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, uint32_t K,
+                      int32_t x0, int32_t y0, uint32_t w, uint32_t h, int16_t *out);
+void or_exact_coverage(const int16_t *pts, const uint32_t *cstart, uint32_t n_contours, uint32_t K,
+                       int32_t x0, int32_t y0, uint32_t w_px, uint32_t h_px, uint32_t n, uint8_t *out);
 
 /* ---- a8: Image sinks (Image.zig:44-130, 173-241) ---- */
 void or_gray_rgb(uint8_t val, uint8_t rgb[3]);                                  /* :78-82 */

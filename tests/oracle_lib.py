@@ -48,6 +48,10 @@ class Oracle:
         L.or_winding_in_glyph.restype = C.c_int16
         L.or_winding_in_glyph.argtypes = [V, V, C.c_uint32, V, V, C.c_int16, C.c_int16]
         L.or_winding_lattice.argtypes = [V, V, C.c_uint32, V, V]
+        L.or_exact_lattice.argtypes = [V, V, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, V]
+        L.or_exact_lattice.restype = None
+        L.or_exact_coverage.argtypes = [V, V, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, V]
+        L.or_exact_coverage.restype = None
         L.or_glyph_debug_render.argtypes = [V, V, C.c_uint32, V, C.c_uint8, V]
         L.or_winding_rgb.argtypes = [C.c_int16, C.c_uint8, C.c_uint8, V]
         L.or_qoi_encode_rgb.restype = C.c_size_t
@@ -136,6 +140,18 @@ class Oracle:
         W, H = int(box[2]) - int(box[0]) + 3, int(box[3]) - int(box[1]) + 3
         out = np.zeros((H, W), np.int16)
         self.lib.or_winding_lattice(_p(pts), _p(cs), nc, _p(box), _p(out))
+        return out
+
+    def exact_lattice(self, glyph, K, x0, y0, w, h) -> np.ndarray:
+        pts, cs, nc = self._g(glyph)
+        out = np.zeros((h, w), np.int16)
+        self.lib.or_exact_lattice(_p(pts), _p(cs), nc, K, x0, y0, w, h, _p(out))
+        return out
+
+    def exact_coverage(self, glyph, K, x0, y0, w_px, h_px, n) -> np.ndarray:
+        pts, cs, nc = self._g(glyph)
+        out = np.zeros((h_px, w_px), np.uint8)
+        self.lib.or_exact_coverage(_p(pts), _p(cs), nc, K, x0, y0, w_px, h_px, n, _p(out))
         return out
 
     def glyph_debug_render(self, glyph, winding_scale) -> np.ndarray:

@@ -210,6 +210,36 @@ def test_exact_integer_path(ctx, oracle, ascii_set):
     assert np.array_equal(fr.windingInGlyph(gg, None, qq, ctx=ctx), oracle.winding_in_glyph(gg, qq))
 
 
+def test_exact_lattice_k_and_coverage(ctx, oracle, ascii_set):
+    """SURVEY §8 f-3 (build-defined): a4-a7 on the glyph scaled by K at integer lattice points, and
+    the n x n box-filtered coverage built on it — bit-exact vs the oracle's twin; K = 1 with the
+    GlyphDebug origin is the reference's own lattice"""
+    for font, ch in [("STIX", "A"), ("DejaVu", "8"), ("STIX", "@")]:
+        g = ascii_set.glyph(ascii_set.find(font, ch))
+        box = g.box.as_array().astype(int)
+        W, H = box[2] - box[0] + 3, box[3] - box[1] + 3
+        assert np.array_equal(fr.exact_lattice(g, 1, box[0] - 1, box[3] + 1, W, H, ctx=ctx), fr.winding_lattice(g, ctx=ctx))
+        for K in (2, 3, 8):
+            # a window of the K-refined lattice around the top-left quarter of the glyph
+            x0, y0 = K * (box[0] - 2), K * (box[3] + 2)
+            w, h = 97, 83
+            assert np.array_equal(fr.exact_lattice(g, K, x0, y0, w, h, ctx=ctx), oracle.exact_lattice(g, K, x0, y0, w, h)), (font, ch, K)
+        # 4 x 4 lattice points per pixel at 1/8 font unit spacing (K = 8), 40 x 30 pixels over the glyph's centre
+        K, n = 8, 4
+        cx, cy = (box[0] + box[2]) // 2, (box[1] + box[3]) // 2
+        got = fr.exact_coverage(g, K, K * cx - 80, K * cy + 60, 40, 30, n, ctx=ctx)
+        assert np.array_equal(got, oracle.exact_coverage(g, K, K * cx - 80, K * cy + 60, 40, 30, n)), (font, ch)
+    # a coarse whole-glyph coverage: K = 1, n = 4 -> one pixel per 4 x 4 font units
+    g = ascii_set.glyph(ascii_set.find("STIX", "g"))
+    box = g.box.as_array().astype(int)
+    wp, hp = (box[2] - box[0]) // 4 + 2, (box[3] - box[1]) // 4 + 2
+    got = fr.exact_coverage(g, 1, box[0] - 2, box[3] + 2, wp, hp, 4, ctx=ctx)
+    assert np.array_equal(got, oracle.exact_coverage(g, 1, box[0] - 2, box[3] + 2, wp, hp, 4))
+    assert got.max() == 255 and got.min() == 0
+    with pytest.raises(fr.FrError):
+        fr.exact_lattice(g, 9, 0, 0, 4, 4, ctx=ctx)          # K > 8 could leave the 128-bit range
+
+
 def test_full_size_properties_config3(ctx):
     """BASELINE configs[2] at FULL size (20 992 glyphs x 256^2, S = 128, 16 samples/pixel, 1.376
     Gpixel): too big for the oracle, so size-independent properties — re-render is idempotent,

@@ -212,3 +212,22 @@ def test_known_answers(oracle, ascii_set):
     import make_known_answers
     got = make_known_answers.compute(oracle, ascii_set)
     assert got == ka
+
+
+def test_exact_lattice_k_twin(oracle, ascii_set):
+    """SURVEY §8 f-3 (build-defined, no reference semantics): K = 1 at the GlyphDebug origin is
+    or_winding_lattice; a glyph whose straight edges carry EXACT midpoints has the same winding at
+    K * p on the K-scaled glyph as at p on the original (only the +-1 'straight' tolerance of
+    render_glyph.zig:99,103 depends on the scale)"""
+    g = ascii_set.glyph(ascii_set.find("STIX", "A"))
+    box = g.box.as_array().astype(int)
+    W, H = box[2] - box[0] + 3, box[3] - box[1] + 3
+    assert np.array_equal(oracle.exact_lattice(g, 1, box[0] - 1, box[3] + 1, W, H), oracle.winding_lattice(g))
+    from font_renderer_amd.glyph import Box, Contour, Glyph
+    sq = np.array([(0, 0), (0, 10), (0, 20), (10, 20), (20, 20), (20, 10), (20, 0), (10, 0), (0, 0)], np.int16)
+    gq = Glyph(Box(0, 0, 20, 20), [Contour(sq)])
+    l1 = oracle.exact_lattice(gq, 1, -2, 22, 25, 25)
+    l4 = oracle.exact_lattice(gq, 4, -8, 88, 97, 97)
+    assert np.array_equal(l4[::4, ::4], l1)
+    cov = oracle.exact_coverage(gq, 4, -8, 88, 24, 24, 4)
+    assert cov[10, 10] == 255 and cov[0, 0] == 0
