@@ -71,6 +71,7 @@ SYMBOLS = [
     ("fr_qoi_bound", C.c_size_t, [C.c_uint32, C.c_uint32]),
     ("fr_qoi_encode_rgb", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("fr_qoi_encode_gray", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("fr_selftest_sqrt", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("fr_selftest_division", C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 

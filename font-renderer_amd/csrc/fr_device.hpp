@@ -47,6 +47,23 @@ __device__ __forceinline__ float div_by_int(float x, float d, float rd)
     const float r = __builtin_fmaf(-q, d, x);
     return __builtin_fmaf(r, rd, q);
 }
+// Correctly rounded sqrt for the arguments the path can produce: delta of render_glyph.zig:58 is
+// 0, negative, or at least 2^-24 in magnitude (c1, c2 are integers, |a| >= 1, and a non-zero ray
+// height is at least 2^-23: DESIGN.md §3), never a denormal — so the 2^32 pre-scaling of the
+// general lowering is dead weight.  v_sqrt_f32 is within 1 ulp; the two FMA residuals pick the
+// neighbour exactly as the compiler's own lowering does.  Negative -> NaN, 0 -> 0.  Not taken on
+// trust: fr_selftest_sqrt compares it with __builtin_sqrtf for EVERY binary32 in [2^-30, 2^66).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x);          // x - (s - ulp) * s
+    const float rp = __builtin_fmaf(-sp, s, x);          // x - (s + ulp) * s
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
 enum : uint32_t {
     REC_LINEAR = 1u,     // a == 0 branch
     REC_NEG_ROOT = 2u,   // t- = (B - sqrt(delta)) / a ; otherwise t+

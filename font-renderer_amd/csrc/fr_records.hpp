@@ -177,7 +177,7 @@ __device__ __forceinline__ int classify_row(const Rec &r, float cy)
 {
     const bool lin = (r.flags & REC_LINEAR) != 0;
     const float delta = cy * r.a + r.c1 - r.c2;                                  // :58
-    const float sq = __builtin_sqrtf(delta);
+    const float sq = sqrt_rn(delta);
     const float num = lin ? (cy - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));   // :51 / :60-61
     const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);
     // t falls with cy for the t- root and for a descending line

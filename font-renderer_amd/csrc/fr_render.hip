@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (r.flags & REC_LINEAR) != 0;
                 const float delta = cyr * r.a + r.c1 - r.c2;
-                const float sq = __builtin_sqrtf(delta);
+                const float sq = sqrt_rn(delta);                               // == sqrt(delta), fr_device.hpp
                 const float num = lin ? (cyr - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));
                 const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);     // == num / d, see fr_device.hpp
                 // the row range brackets the accepted set; the reference's own tests decide (:52, :59, :64)
@@ -601,6 +601,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             if (px0 < sw) {
 #endif
                 const uint32_t nvalid = min(16u, sw - px0);
+                // my window's bytes of pixel row yl start at dst0 + yl * stride; whether the 16-byte
+                // store applies is decided once (a full window, 16-byte aligned in every row)
+                uint8_t *const dst0 = reinterpret_cast<uint8_t *>(A.out) + out_row0 * A.out_stride + out_col0 + px0;
+                const bool vec_store = nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst0) | (uintptr_t)A.out_stride) & 15u) == 0;
                 for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) {
                     unsigned long long mask[N];
 #pragma unroll
@@ -647,11 +651,11 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                             pk[p >> 2] |= v << (8 * (p & 3));
                         }
                     }
-                    uint8_t *dst = reinterpret_cast<uint8_t *>(A.out) + (out_row0 + yl) * A.out_stride + out_col0 + px0;
+                    uint8_t *dst = dst0 + (size_t)yl * A.out_stride;
 #if defined(FR_ABLATE) && FR_ABLATE == 13
                     if ((pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) == 0x12345678u) {        // timing-only: windows computed, (almost) never stored
 #else
-                    if (nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+                    if (vec_store) {
 #endif
                         *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                     } else {

@@ -41,7 +41,48 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(uint32_t d_lo, uint32
     }
 }
 
+// sqrt_rn (fr_device.hpp) == the correctly rounded square root for every binary32 whose exponent
+// field lies in [e_lo, e_hi] (positive, normal): one block row per exponent, all 2^23 significands.
+__global__ __launch_bounds__(256) void selftest_sqrt_kernel(uint32_t e_lo, unsigned long long *mismatches, uint32_t *first_bad)
+{
+    const uint32_t e = e_lo + blockIdx.x / 32u, part = blockIdx.x % 32u;
+    uint32_t bad = 0, bad_x = 0;
+    for (uint32_t m = part * 256u + threadIdx.x; m < (1u << 23); m += 32u * 256u) {
+        const uint32_t bits = (e << 23) | m;
+        const float x = __uint_as_float(bits);
+        if (__float_as_uint(sqrt_rn(x)) != __float_as_uint(__builtin_sqrtf(x))) { ++bad; bad_x = bits; }
+    }
+    if (bad) {
+        atomicAdd(mismatches, (unsigned long long)bad);
+        first_bad[0] = bad_x;
+    }
+}
+
 }  // namespace fr
+
+extern "C" int fr_selftest_sqrt(uint64_t *mismatches, uint32_t *bad_x_bits)
+{
+    if (!mismatches) return FR_E_INVALID;
+    unsigned long long *d_m = nullptr;
+    uint32_t *d_b = nullptr;
+    if (hipMalloc(&d_m, 8) != hipSuccess || hipMalloc(&d_b, 8) != hipSuccess) return FR_E_HIP;
+    (void)hipMemset(d_m, 0, 8);
+    (void)hipMemset(d_b, 0, 8);
+    // exponent fields 97 .. 192: [2^-30, 2^66) covers every delta the path can form (and then some)
+    const uint32_t e_lo = 97u, e_hi = 192u;
+    hipLaunchKernelGGL(fr::selftest_sqrt_kernel, dim3((e_hi - e_lo + 1u) * 32u), dim3(256), 0, 0, e_lo, d_m, d_b);
+    // the two special arguments: 0 -> 0, negative -> NaN are checked on the host side of the test
+    unsigned long long m = 0;
+    uint32_t b = 0;
+    hipError_t e = hipMemcpy(&m, d_m, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&b, d_b, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_m);
+    (void)hipFree(d_b);
+    if (e != hipSuccess) return FR_E_HIP;
+    *mismatches = m;
+    if (bad_x_bits) *bad_x_bits = b;
+    return FR_OK;
+}
 
 extern "C" int fr_selftest_division(uint32_t d_lo, uint32_t d_hi, uint64_t *mismatches,
                                     uint32_t *bad_divisor, uint32_t *bad_x_bits)

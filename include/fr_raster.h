@@ -223,6 +223,10 @@ int fr_qoi_encode_gray(const uint8_t *gray, uint32_t width, uint32_t height, siz
  * admissible.  The full range 1..131072 takes a few seconds.                              */
 int fr_selftest_division(uint32_t d_lo, uint32_t d_hi, uint64_t *mismatches,
                          uint32_t *bad_divisor, uint32_t *bad_x_bits);
+/* The render kernel's square root (delta of render_glyph.zig:60) skips the denormal pre-scaling of
+ * the general lowering; this compares it with the correctly rounded sqrt for every binary32 in
+ * [2^-30, 2^66) on the device.  *mismatches must come back 0.                                  */
+int fr_selftest_sqrt(uint64_t *mismatches, uint32_t *bad_x_bits);
 
 #ifdef __cplusplus
 }

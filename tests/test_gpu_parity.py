@@ -326,6 +326,18 @@ def test_division_shortcut_is_exact_exhaustively(ctx):
     assert m.value == 0, f"{m.value} mismatches, e.g. divisor {bd.value}, x bits {bx.value:#x}"
 
 
+def test_sqrt_shortcut_is_exact_exhaustively(ctx):
+    """sqrt_rn (v_sqrt_f32 + two FMA residuals, no denormal pre-scaling) == the correctly rounded
+    sqrt for EVERY binary32 in [2^-30, 2^66) — run on the device.  Proof obligation for using it
+    for render_glyph.zig:60's std.math.sqrt; delta is 0, negative or >= 2^-24."""
+    import ctypes as C
+    from font_renderer_amd import _lib
+    lib = _lib.load_library()
+    m, bx = C.c_uint64(1), C.c_uint32()
+    _lib.check(lib.fr_selftest_sqrt(C.byref(m), C.byref(bx)))
+    assert m.value == 0, f"{m.value} mismatches, e.g. x bits {bx.value:#x}"
+
+
 def test_whole_font_from_the_c_side_producer(ctx, oracle):
     """SURVEY §8f-1 end to end: TrueType bytes -> fr_font_* (C++ contour producer) -> glyph set ->
     one atlas of every glyph the reference could load (DejaVuSerif-Italic: ~3 000 glyphs incl.
