@@ -76,12 +76,6 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x)
 #ifndef FR_BAND_PARTS
 #define FR_BAND_PARTS 1
 #endif
-// 2: every record carries its exact sample-row range; a band's (record, row) pairs are laid out
-//    by a prefix sum and decoded by a marker + max-scan (load-balanced expansion, no per-record loop)
-// 1: per-record ballot scan against [lo, hi] (previous scheme, kept for A/B timing)
-#ifndef FR_WALK
-#define FR_WALK 2
-#endif
 // One crossing = 16 bits: (J << 2) | code, J <= 1024 sample columns of a strip, winding step = code - 1
 // (code 2: +1, code 0: -1).  An unused slot is 0xfffd: it sorts last and its step is 0, so the
 // suffix sums and the toggle test need no "is this slot used" case.
@@ -223,7 +217,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         return ((float)(job.max_y - (int32_t)(r / N)) - sub_off((int)(r % N), N, phase)) / job.scale;
     };
     auto stage = [&](Rec r) {
-#if FR_WALK == 2
         uint32_t ra = 1u, re = 0u;
         if (r.lo <= r.hi) {
             const float ph = phase ? 0.5f : 0.0f, top = (float)(Hs - 1u);
@@ -242,7 +235,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         }
         r.lo = __builtin_bit_cast(float, ra);
         r.hi = __builtin_bit_cast(float, re);
-#endif
         return r;
     };
     if (A.fused) {
@@ -253,18 +245,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         const uint32_t s0g = A.glyph_seg_start[g];
         if (tid < rec_cnt) {
             Rec r;
-#if FR_WALK == 2
             RowGeom geo;
             geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
             build_record_rows(A.pts + 2u * (size_t)A.seg_p0[s0g + (tid >> 1)], tid & 1u, geo, r);
             s_rec[tid] = r;
-#else
-            if (!build_record(A.pts + 2u * (size_t)A.seg_p0[s0g + (tid >> 1)], tid & 1u, r)) {
-                r.lo = __builtin_inff(); r.hi = -__builtin_inff();
-                r.a = 1.f; r.b = 0.f; r.c1 = 0.f; r.c2 = 0.f; r.ax = 0.f; r.bx = 0.f; r.p0x = 0.f; r.flags = 0; r.rden = 1.f; r.pad1 = 0;
-            }
-            s_rec[tid] = stage(r);
-#endif
         }
     } else {
         // stage the first (usually only) 256-record chunk: one record per lane, issued first so
@@ -286,6 +270,19 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
     const size_t out_col0 = (size_t)job.out_x + x0s;
     __syncthreads();                            // the ONLY workgroup barrier for glyphs of <= 256 records
+    // a glyph whose records fit one LDS chunk (all but pathological ones): every lane keeps the row
+    // ranges of records 4*lane .. 4*lane + 3 in registers for all its bands (consecutive, so that the
+    // record index grows along the pair sequence: the marker decode is a max-scan)
+    const bool one_chunk = rec_cnt <= RCHUNK;   // workgroup-uniform
+    uint32_t rra[4], rre[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = 4u * lane + (uint32_t)i;
+        const bool have = one_chunk && k < rec_cnt;
+        const uint32_t kk = have ? k : 0u;
+        rra[i] = have ? __builtin_bit_cast(uint32_t, s_rec[kk].lo) : 1u;
+        rre[i] = have ? __builtin_bit_cast(uint32_t, s_rec[kk].hi) : 0u;
+    }
     STAMP(0);                                   // setup: job, record staging, cx table
 
   // wave w takes wave bands band_first + w, + 4, ...; every wave runs the same trip count so the
@@ -300,11 +297,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const bool row_valid = lane < nrows;
     const uint32_t rr0 = row_valid ? lane : 0u;
     const float cy = ((float)(job.max_y - (int32_t)(y0 + rr0 / N)) - sub_off((int)(rr0 % N), N, phase)) / job.scale;
-#if FR_WALK != 2
-    // cy is non-increasing in the row index: this wave spans [wcy_bot, wcy_top]
-    const float wcy_top = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cy)));
-    const float wcy_bot = bcast(cy, nrows ? nrows - 1u : 0u);
-#endif
 
     // my row's crossings are APPENDED to a wave-private LDS list during the walk (one
     // ds_write_b16 each) and sorted once afterwards; the list lives where the window masks
@@ -329,7 +321,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     s_cy[lane] = cy;
     s_cnt[lane] = 0u;
     uint32_t npairs = 0;                        // wave-uniform
-#if FR_WALK == 2
     // s_pairs holds MARKERS: slot `off` of the pair sequence holds k + 1 where record k's run of
     // pairs starts, 0 elsewhere; a max-scan over the slots recovers every pair's record
     auto zero_markers = [&]() {
@@ -339,37 +330,24 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     };
     zero_markers();
     const uint32_t row_b0 = band * 64u;         // first sample row of my band (global in the cell)
-#else
-    const float cy_scan = row_valid ? cy : __builtin_nanf("");
-#endif
     auto eval_pairs = [&]() {
         wave_lds_sync();
         STAMP(1);                               // pair layout
         COUNT(9, npairs);
-#if FR_WALK == 2
         uint32_t carry = 0;
-#endif
         for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
             const uint32_t p = p0 + lane;
-#if FR_WALK == 2
             const uint32_t mk = (p < npairs) ? (uint32_t)s_pairs[p] : 0u;
             const uint32_t k1 = max(wave_incl_max(mk), carry);
             carry = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
-#endif
 #if defined(FR_ABLATE) && FR_ABLATE == 10
             if (p < npairs && A.n_jobs == 0xffffffffu) {    // timing-only: pairs are collected, never evaluated
 #else
             if (p < npairs) {
 #endif
-#if FR_WALK == 2
                 const uint32_t kk = k1 - 1u;
                 const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]);
                 const Rec r = s_rec[kk];
-#else
-                const uint32_t pr = s_pairs[p];
-                const uint32_t row = pr & 63u;
-                const Rec r = s_rec[pr >> 6];
-#endif
                 const float cyr = s_cy[row];
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (r.flags & REC_LINEAR) != 0;
@@ -415,7 +393,44 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         STAMP(2);                               // pair evaluation
     };
 
-    for (uint32_t base = 0; base < rec_cnt; base += RCHUNK) {
+    // fast layout: all (<= 256) records in ONE prefix sum — a lane's four runs follow one another
+    bool laid_out = false;
+    if (one_chunk) {
+        uint32_t c[4], r0[4], csum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0[i] = max(rra[i], row_b0);
+            const uint32_t r1 = min(rre[i], row_b0 + nrows);
+            c[i] = r1 > r0[i] ? r1 - r0[i] : 0u;
+            csum += c[i];
+        }
+#if defined(FR_ABLATE) && FR_ABLATE == 8
+        csum = (A.n_jobs == 0xffffffffu) ? csum : 0u;                  // timing-only: no walk
+#endif
+        const uint32_t incl = wave_incl_add(csum);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (tot <= PCAP) {                      // (wave-uniform) else: the generic path below, with flushes
+            uint32_t off = incl - csum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#if defined(FR_ABLATE) && FR_ABLATE == 8
+                if (c[i] && A.n_jobs == 0xffffffffu) {
+#else
+                if (c[i]) {
+#endif
+                    const uint32_t k = 4u * lane + (uint32_t)i;
+                    s_pairs[off] = (uint16_t)(k + 1u);
+                    s_roff[k] = (int16_t)((int32_t)(r0[i] - row_b0) - (int32_t)off);
+                }
+                off += c[i];
+            }
+            npairs = tot;
+            if (npairs) eval_pairs();
+            laid_out = true;
+        }
+    }
+
+    for (uint32_t base = 0; base < rec_cnt && !laid_out; base += RCHUNK) {
         if (rec_cnt > RCHUNK) {                   // multi-chunk glyph: restage (workgroup-uniform path)
             __syncthreads();
             if (tid < RCHUNK && base + tid < rec_cnt) s_rec[tid] = stage(grec[base + tid]);
@@ -426,7 +441,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #else
         const uint32_t nchunk = min(RCHUNK, rec_cnt - base);
 #endif
-#if FR_WALK == 2
         for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
             // lane = record: clip its row range to my band, prefix-sum the run lengths
             const uint32_t k = cb + lane;
@@ -452,28 +466,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             }
         }
         if (npairs) { eval_pairs(); if (base + RCHUNK < rec_cnt) zero_markers(); }   // before the staged records are replaced / the band ends
-#else
-        for (uint32_t cb = 0; cb < nchunk && nrows; cb += 64u) {
-            const uint32_t mi = min(cb + lane, nchunk - 1u);
-            const float mlo = s_rec[mi].lo, mhi = s_rec[mi].hi;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64((cb + lane < nchunk) & (mhi >= wcy_bot) & (mlo <= wcy_top));
-            while (todo) {
-                const uint32_t kk = (uint32_t)__builtin_ctzll(todo);
-                const uint32_t k = cb + kk;
-                todo &= todo - 1ull;
-                // the record's bounds come from the lane that already holds them (v_readlane): no
-                // LDS round trip on the scan's critical path
-                const float klo = bcast(mlo, kk), khi = bcast(mhi, kk);
-                const bool want = (cy_scan >= klo) & (cy_scan <= khi);       // NaN for rows past the band
-                const unsigned long long wl = __builtin_amdgcn_ballot_w64(want);
-                if (!wl) continue;
-                if (npairs > PCAP - 64u) eval_pairs();                      // a record adds at most 64 pairs
-                if (want) s_pairs[npairs + (uint32_t)__popcll(wl & ((1ull << lane) - 1ull))] = (uint16_t)((k << 6) | lane);
-                npairs += (uint32_t)__popcll(wl);
-            }
-        }
-        if (npairs) eval_pairs();               // before the staged records are replaced / the band ends
-#endif
     }
     cnt = s_cnt[lane];
     COUNT(8, 1);                                // wave bands
