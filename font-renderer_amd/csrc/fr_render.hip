@@ -109,6 +109,7 @@ constexpr uint32_t RCHUNK = 256u;
 #define FR_WG_WAVES 4
 #endif
 constexpr uint32_t NW = FR_WG_WAVES;
+constexpr uint32_t TAIL_BYTES = (64u / FR_BAND_PARTS) * 4u;   // per-wave LDS tail: fill parity word of every sample row
 // Diagnostic build only (make STAMPS=1 -> libfr_raster_stamps.so): per-phase shader-clock
 // sums of wave 0 of every workgroup, added to a buffer nothing else reads.  The shipped
 // library is built without FR_STAMPS and executes no stamp.
@@ -158,11 +159,11 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 template <int MODE, int N, int CAP>
-#ifdef FR_WAVES_PER_EU
-#define FR_OCC __attribute__((amdgpu_waves_per_eu(FR_WAVES_PER_EU, FR_WAVES_PER_EU)))
-#else
-#define FR_OCC
+// three workgroups fit a CU's LDS: hold the register allocation to three waves per SIMD (<= 168 VGPRs)
+#ifndef FR_WAVES_PER_EU
+#define FR_WAVES_PER_EU 3
 #endif
+#define FR_OCC __attribute__((amdgpu_waves_per_eu(FR_WAVES_PER_EU, FR_WAVES_PER_EU)))
 __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const RenderArgs A)
 {
     constexpr uint32_t WBAND = 64u / N;         // pixel rows per wave band (64 sample rows)
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     unsigned char *wregion = smem + A.lds_region + A.lds_rec_bytes + (size_t)wave * A.lds_wave_bytes;
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(wregion);    // [32][nwin_pad]
     uint32_t *s_row = reinterpret_cast<uint32_t *>(wregion);                         // [32][CAP]
-    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail) + wave * PROWS_S; // [PROWS_S]
+    uint32_t *s_fill = reinterpret_cast<uint32_t *>(smem + A.lds_tail + (size_t)wave * TAIL_BYTES);   // [PROWS_S]
 
     // Every staged record swaps its bracket [lo, hi] (ray heights) for the EXACT half-open range
     // [ra, re) of this cell's sample rows whose cy lies in it — cy(r) is non-increasing in r, so
@@ -585,77 +586,82 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             STAMP(4);                           // phase 1b: zero + toggles
 
             // ---- phase 2: one lane per 16-pixel window
-            const uint32_t wx = lane & (nwin_pad - 1u);
-            const uint32_t px0 = wx * 16u;
-#if defined(FR_ABLATE) && FR_ABLATE == 3
-            if (px0 < sw && A.n_jobs == 0xffffffffu) {      // timing-only: no windows, no stores
-#else
-            if (px0 < sw) {
-#endif
-                const uint32_t nvalid = min(16u, sw - px0);
-                // my window's bytes of pixel row yl start at dst0 + yl * stride; whether the 16-byte
-                // store applies is decided once (a full window, 16-byte aligned in every row)
-                uint8_t *const dst0 = reinterpret_cast<uint8_t *>(A.out) + out_row0 * A.out_stride + out_col0 + px0;
-                const bool vec_store = nvalid == 16u && ((reinterpret_cast<uintptr_t>(dst0) | (uintptr_t)A.out_stride) & 15u) == 0;
-                for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) {
-                    unsigned long long mask[N];
-#pragma unroll
-                    for (int rr = 0; rr < N; ++rr) {
-                        const uint32_t r = yl * N + rr;
-                        const unsigned long long mk = s_mask[(mask_line(r) << nwin_log) + wx];
-                        // "windows left of a toggle are filled" parity of this window: 0 or all ones
-                        const uint32_t fl = (uint32_t)__builtin_amdgcn_sbfe((int)s_fill[r], wx, 1u);
-                        mask[rr] = mk ^ (((unsigned long long)(fl & (uint32_t)(WALL >> 32)) << 32) | (fl & (uint32_t)WALL));
-                    }
-                    uint32_t pk[4];
-                    if (N == 4) {
-                        // SWAR per 32-bit half (8 pixels x 4 sample columns), the two halves never
-                        // exchange bits: pair counts, then the even / odd pairs of every nibble summed
-                        // over the 4 sample rows (<= 8 each), then even / odd pixels as bytes (<= 16)
-#pragma unroll
-                        for (int hlf = 0; hlf < 2; ++hlf) {
-                            uint32_t pa = 0, pb = 0;
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) {
-                                uint32_t x = (uint32_t)(mask[rr] >> (32 * hlf));
-                                x = x - ((x >> 1) & 0x55555555u);
-                                pa += x & 0x33333333u;
-                                pb += (x >> 2) & 0x33333333u;
-                            }
-                            const uint32_t M = 0x0f0f0f0fu;
-                            const uint32_t ke = (pa & M) + (pb & M);                    // even pixels, 0..16
-                            const uint32_t ko = ((pa >> 4) & M) + ((pb >> 4) & M);      // odd pixels
-                            // round_half_up(255*k/16) = 16k - (k > 8), per byte
-                            const uint32_t ve = (ke << 4) - (((ke + 0x07070707u) >> 4) & 0x01010101u);
-                            const uint32_t vo = (ko << 4) - (((ko + 0x07070707u) >> 4) & 0x01010101u);
-                            pk[2 * hlf + 0] = __builtin_amdgcn_perm(vo, ve, 0x05010400u);
-                            pk[2 * hlf + 1] = __builtin_amdgcn_perm(vo, ve, 0x07030602u);
-                        }
-                    } else {
-                        pk[0] = pk[1] = pk[2] = pk[3] = 0;
-#pragma unroll
-                        for (int p = 0; p < 16; ++p) {
-                            uint32_t k = 0;
-#pragma unroll
-                            for (int rr = 0; rr < N; ++rr)
-                                k += (uint32_t)__popc((uint32_t)(mask[rr] >> (p * N)) & ((1u << N) - 1u));
-                            const uint32_t v = (2u * 255u * k + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
-                            pk[p >> 2] |= v << (8 * (p & 3));
-                        }
-                    }
-                    uint8_t *dst = dst0 + (size_t)yl * A.out_stride;
+            // window (yl, wx) = pixels [16 wx, 16 wx + 16) of the half's pixel row yl.  Whether 16-byte
+            // stores apply is one wave-uniform fact (windows are 16 bytes apart) plus "the window is full".
+            uint8_t *const out_half = reinterpret_cast<uint8_t *>(A.out) + out_row0 * A.out_stride + out_col0;
+            const bool aligned16 = ((reinterpret_cast<uintptr_t>(out_half) | (uintptr_t)A.out_stride) & 15u) == 0;
+            auto store_window = [&](uint32_t yl, uint32_t wxx, const uint32_t (&pk)[4]) {
+                const uint32_t px = wxx * 16u;
+                uint8_t *dst = out_half + (size_t)yl * A.out_stride + px;
 #if defined(FR_ABLATE) && FR_ABLATE == 13
-                    if ((pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) == 0x12345678u) {        // timing-only: windows computed, (almost) never stored
+                if ((pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) == 0x12345678u) {            // timing-only: windows computed, (almost) never stored
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
 #else
-                    if (vec_store) {
+                if (aligned16 && sw - px >= 16u) {
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                } else {
+                    const uint32_t nvalid = min(16u, sw - px);
+                    for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
+                }
 #endif
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                    } else {
-#if !(defined(FR_ABLATE) && FR_ABLATE == 13)
-                        for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
-#endif
+            };
+            auto popcount_window = [&](uint32_t yl, uint32_t wxx) {
+                unsigned long long mask[N];
+#pragma unroll
+                for (int rr = 0; rr < N; ++rr) {
+                    const uint32_t r = yl * N + rr;
+                    const unsigned long long mk = s_mask[(mask_line(r) << nwin_log) + wxx];
+                    // "windows left of a toggle are filled" parity of this window: 0 or all ones
+                    const uint32_t fl = (uint32_t)__builtin_amdgcn_sbfe((int)s_fill[r], wxx, 1u);
+                    mask[rr] = mk ^ (((unsigned long long)(fl & (uint32_t)(WALL >> 32)) << 32) | (fl & (uint32_t)WALL));
+                }
+                uint32_t pk[4];
+                if (N == 4) {
+                    // SWAR per 32-bit half (8 pixels x 4 sample columns), the two halves never
+                    // exchange bits: pair counts, then the even / odd pairs of every nibble summed
+                    // over the 4 sample rows (<= 8 each), then even / odd pixels as bytes (<= 16)
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        uint32_t pa = 0, pb = 0;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            uint32_t x = (uint32_t)(mask[rr] >> (32 * hlf));
+                            x = x - ((x >> 1) & 0x55555555u);
+                            pa += x & 0x33333333u;
+                            pb += (x >> 2) & 0x33333333u;
+                        }
+                        const uint32_t M = 0x0f0f0f0fu;
+                        const uint32_t ke = (pa & M) + (pb & M);                    // even pixels, 0..16
+                        const uint32_t ko = ((pa >> 4) & M) + ((pb >> 4) & M);      // odd pixels
+                        // round_half_up(255*k/16) = 16k - (k > 8), per byte
+                        const uint32_t ve = (ke << 4) - (((ke + 0x07070707u) >> 4) & 0x01010101u);
+                        const uint32_t vo = (ko << 4) - (((ko + 0x07070707u) >> 4) & 0x01010101u);
+                        pk[2 * hlf + 0] = __builtin_amdgcn_perm(vo, ve, 0x05010400u);
+                        pk[2 * hlf + 1] = __builtin_amdgcn_perm(vo, ve, 0x07030602u);
+                    }
+                } else {
+                    pk[0] = pk[1] = pk[2] = pk[3] = 0;
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        uint32_t k = 0;
+#pragma unroll
+                        for (int rr = 0; rr < N; ++rr)
+                            k += (uint32_t)__popc((uint32_t)(mask[rr] >> (p * N)) & ((1u << N) - 1u));
+                        const uint32_t v = (2u * 255u * k + (uint32_t)(N * N)) / (2u * (uint32_t)(N * N));
+                        pk[p >> 2] |= v << (8 * (p & 3));
                     }
                 }
+                store_window(yl, wxx, pk);
+            };
+            const uint32_t wx = lane & (nwin_pad - 1u);
+#if defined(FR_ABLATE) && FR_ABLATE == 3
+            const bool win_on = A.n_jobs == 0xffffffffu;    // timing-only: no windows, no stores
+#else
+            const bool win_on = true;
+#endif
+            if (wx * 16u < sw && win_on) {
+                for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) popcount_window(yl, wx);
             }
             wave_lds_sync();                    // masks are re-zeroed by the next half / band
             STAMP(5);                           // phase 2: windows + stores
@@ -811,7 +817,7 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     const size_t t = cx + rb + NW * wb;
     *rec_bytes = (uint32_t)rb;
     *nwin_log = lg; *region = (uint32_t)cx; *wave_bytes = (uint32_t)wb; *tail = (uint32_t)t;
-    *total = t + NW * prow * 4;
+    *total = t + NW * TAIL_BYTES;
 }
 
 template <int MODE, int N, int CAP>
