@@ -527,6 +527,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     }
     // slots in use in the wave's fullest row: the toggle loop visits no more
     const uint32_t maxcnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(min(cnt, (uint32_t)CAP)), 63);
+    COUNT(10, (unsigned long long)(maxcnt <= 8u) | ((unsigned long long)(maxcnt > 8u && maxcnt <= 12u) << 16) |
+                  ((unsigned long long)(maxcnt > 12u && maxcnt <= 16u) << 32) | ((unsigned long long)(maxcnt > 16u) << 48));
     wave_lds_sync();                            // the list region becomes the mask region below
     STAMP(3);                                   // list pull + sort
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
@@ -661,6 +663,9 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             const bool win_on = true;
 #endif
             if (wx * 16u < sw && win_on) {
+#ifdef FR_WIN_UNROLL
+#pragma unroll FR_WIN_UNROLL
+#endif
                 for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) popcount_window(yl, wx);
             }
             wave_lds_sync();                    // masks are re-zeroed by the next half / band

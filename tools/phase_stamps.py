@@ -32,3 +32,5 @@ for nme, x in zip(names, v6):
     print(f"{nme:36s} {x / v6.sum() * 100:6.2f} %   {x / G:10.0f} cycles/workgroup (wave 0)")
 bands = max(v[8], 1)
 print(f"wave bands {v[8]:.0f}; per wave band: pairs {v[9] / bands:.1f}, crossings ~{64 * v[11] / bands:.1f}")
+t = int(v[10])
+print("sort tier per wave band (lane 0's wave bands x 2^16 packing): <=8:", t & 0xffff, " 9-12:", (t >> 16) & 0xffff, " 13-16:", (t >> 32) & 0xffff, " >16:", (t >> 48) & 0xffff)
