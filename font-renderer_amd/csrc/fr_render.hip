@@ -103,7 +103,10 @@ __device__ __forceinline__ void sort_network(uint32_t (&e)[32])
                     }
 }
 // records staged in LDS per pass
-constexpr uint32_t RCHUNK = 256u;
+#ifndef FR_RCHUNK
+#define FR_RCHUNK 256
+#endif
+constexpr uint32_t RCHUNK = FR_RCHUNK;
 // waves per workgroup: they share one cell's records and cx table and take its wave bands round-robin
 #ifndef FR_WG_WAVES
 #define FR_WG_WAVES 4
@@ -288,6 +291,9 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 
   // wave w takes wave bands band_first + w, + 4, ...; every wave runs the same trip count so the
   // (rare) multi-chunk restaging barriers line up
+#if defined(FR_ABLATE) && FR_ABLATE == 20
+  if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[1] + rra[2] + rre[3] == 0x12345u) s_fill[0] = 1u; return; }   // timing-only: set-up alone
+#endif
   for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
     const uint32_t band = band0 + wave;
     const bool band_valid = band < band_end;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             const uint32_t mk = (p < npairs) ? (uint32_t)s_pairs[p] : 0u;
             const uint32_t k1 = max(wave_incl_max(mk), carry);
             carry = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
-#if defined(FR_ABLATE) && FR_ABLATE == 10
+#if defined(FR_ABLATE) && (FR_ABLATE == 10 || FR_ABLATE == 21)
             if (p < npairs && A.n_jobs == 0xffffffffu) {    // timing-only: pairs are collected, never evaluated
 #else
             if (p < npairs) {
@@ -481,7 +487,11 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         const uint32_t prows_b = nrows / N;
         const uint32_t wx = lane & (nwin_pad - 1u);
         const uint32_t px0 = wx * 16u;
+#if defined(FR_ABLATE) && (FR_ABLATE == 21 || FR_ABLATE == 8)
+        if (px0 < sw && A.n_jobs == 0xffffffffu) {      // timing-only: no background stores
+#else
         if (px0 < sw) {
+#endif
             const uint32_t nvalid = min(16u, sw - px0);
             for (uint32_t yl = lane >> nwin_log; yl < prows_b; yl += (64u >> nwin_log)) {
                 const size_t eidx = ((size_t)job.out_y + y0 + yl) * A.out_stride + out_col0 + px0;

@@ -189,6 +189,28 @@ def test_random_scales_and_offsets_property(ctx, oracle):
         assert np.array_equal(got, ref)
 
 
+def test_zoomed_and_shrunk_cells(ctx, oracle, ascii_set):
+    """scales far from the usual size/upm: cells that look at a small part of an outline at 37.5, 1000 and
+    4096 pixels per font unit (pixel coordinates up to 2^22: the affine row guess is off by several rows
+    and the settle loops walk), and whole glyphs squeezed into a few pixels"""
+    i = ascii_set.find("STIX", "g")
+    gs = GlyphSet([ascii_set.glyph(i)])
+    box = gs.boxes[0].astype(np.int64)
+    rows, x = [], 0
+    for s, (fx, fy) in [(37.5, (0.5, 0.5)), (1000.0, (0.3, 0.6)), (4096.0, (0.52, 0.41)), (333.25, (0.1, 0.9))]:
+        ux, uy = box[0] + fx * (box[2] - box[0]), box[1] + fy * (box[3] - box[1])      # font-unit point to look at
+        rows.append((0, int(ux * s) - 30, int(uy * s) + 20, 61, 43, x, 0, np.float32(s)))
+        x += 64
+    for s in (0.004, 0.0009765625, 0.02):
+        rows.append((0, int(np.floor(box[0] * s)) - 2, int(np.ceil(box[3] * s)) + 2, 23, 19, x, 0, np.float32(s)))
+        x += 32
+    jobs = rg.make_jobs(rows)
+    for mode, n, center in [(fr.FR_COVERAGE_U8, 4, True), (fr.FR_COVERAGE_U8, 4, False), (fr.FR_WINDING_I16, 1, False), (fr.FR_COVERAGE_U8, 2, True)]:
+        got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (48, x), n, center)
+        assert np.array_equal(got, ref), (mode, n, center)
+        assert got.any()
+
+
 def test_exact_integer_path(ctx, oracle, ascii_set):
     """GlyphInfo.init + windingInGlyph (render_glyph.zig:76-300) incl. the GlyphDebug lattice"""
     oracle.diag_reset()
