@@ -84,23 +84,48 @@ constexpr uint32_t PCAP = 1024u;               // (record,row) pairs buffered pe
 constexpr uint32_t LSTRIDE = 40u;              // u16 slots per row list: 32 used + pad; an 80-byte
                                                // row stride makes one-row-per-lane b128 reads conflict-free
 
-// Batcher's odd-even merge sort as a fixed compare-exchange network over registers (ascending).
-template <int NN>
-__device__ __forceinline__ void sort_network(uint32_t (&e)[32])
+// Sorting 2H crossings that sit PACKED two per register (d[j] = slot 2j | slot 2j+1 << 16), ascending:
+//   1. Batcher's odd-even merge network over the H registers with v_pk_min_u16 / v_pk_max_u16 — the low
+//      halves and the high halves are sorted as two independent sequences by the same instructions;
+//   2. one "flip" step merges them (low[j] against high[H-1-j]; a half swap, a packed min/max and two
+//      byte permutes per register pair): afterwards every low half <= every high half and both are bitonic;
+//   3. log2(H) half-cleaner stages, again packed.
+// Result: low halves = s[0..H), high halves = s[H..2H).  About half the instructions of the unpacked
+// network, no unpacking, half the registers.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pce(uint32_t &a, uint32_t &b)
+{
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    a = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+    b = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+template <int H>
+__device__ __forceinline__ void packed_sort(uint32_t (&d)[16])
 {
 #pragma unroll
-    for (int p = 1; p < NN; p *= 2)
+    for (int p = 1; p < H; p *= 2)
 #pragma unroll
         for (int k = p; k >= 1; k /= 2)
 #pragma unroll
-            for (int j = k % p; j + k < NN; j += 2 * k)
+            for (int j = k % p; j + k < H; j += 2 * k)
 #pragma unroll
                 for (int i = 0; i < k; ++i)
-                    if (i + j + k < NN && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
-                        const uint32_t lo = min(e[i + j], e[i + j + k]);
-                        e[i + j + k] = max(e[i + j], e[i + j + k]);
-                        e[i + j] = lo;
-                    }
+                    if (i + j + k < H && (i + j) / (2 * p) == (i + j + k) / (2 * p)) pce(d[i + j], d[i + j + k]);
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) {
+        const uint32_t x = d[j], y = d[H - 1 - j];
+        const uint32_t ys = __builtin_amdgcn_alignbit(y, y, 16);                    // halves swapped
+        const u16x2 xv = __builtin_bit_cast(u16x2, x), yv = __builtin_bit_cast(u16x2, ys);
+        const uint32_t mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(xv, yv));
+        const uint32_t mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(xv, yv));
+        d[j] = __builtin_amdgcn_perm(mx, mn, 0x05040100u);                          // min of pair j | max of pair j
+        d[H - 1 - j] = __builtin_amdgcn_perm(mx, mn, 0x07060302u);                  // the same of pair H-1-j
+    }
+#pragma unroll
+    for (int k = H / 2; k >= 1; k /= 2)
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            if (!(j & k)) pce(d[j], d[j + k]);
 }
 // records staged in LDS per pass
 #ifndef FR_RCHUNK
@@ -360,7 +385,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 const bool lin = (r.flags & REC_LINEAR) != 0;
                 const float delta = cyr * r.a + r.c1 - r.c2;
                 const float sq = sqrt_rn(delta);                               // == sqrt(delta), fr_device.hpp
-                const float num = lin ? (cyr - r.b) : ((r.flags & REC_NEG_ROOT) ? (r.b - sq) : (r.b + sq));
+                // B - sqrt == B + (-sqrt) bit for bit: the t- root flips the sign bit (REC_NEG_ROOT is bit 1)
+                const float sqs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sq) ^ ((r.flags & REC_NEG_ROOT) << 30));
+                const float numq = r.b + sqs, numl = cyr - r.b;
+                const float num = lin ? numl : numq;
                 const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);     // == num / d, see fr_device.hpp
                 // the row range brackets the accepted set; the reference's own tests decide (:52, :59, :64)
                 const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
@@ -518,22 +546,19 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     }
     // ---- pull my list into registers and sort it by J (network size = the wave's fullest row)
     const bool ovf = cnt > (uint32_t)CAP;
-    uint32_t e[32];
+    uint32_t d[16];                             // two slots per register
+    uint32_t Hcur;                              // registers in use: sorted slot i sits in d[i % Hcur], half i / Hcur
     {
         const uint4 *f = reinterpret_cast<const uint4 *>(mylist);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 v = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
             if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = f[q];
-            e[8 * q + 0] = v.x & 0xffffu; e[8 * q + 1] = v.x >> 16; e[8 * q + 2] = v.y & 0xffffu; e[8 * q + 3] = v.y >> 16;
-            e[8 * q + 4] = v.z & 0xffffu; e[8 * q + 5] = v.z >> 16; e[8 * q + 6] = v.w & 0xffffu; e[8 * q + 7] = v.w >> 16;
+            d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
         }
-        // the generator handles any width: 5 tiers keep the comparator count near the need
-        if (CAP > 24 && __ballot(cnt > 24u) != 0ull) sort_network<32>(e);
-        else if (CAP > 16 && __ballot(cnt > 16u) != 0ull) sort_network<24>(e);
-        else if (CAP > 12 && __ballot(cnt > 12u) != 0ull) sort_network<16>(e);
-        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) sort_network<12>(e);
-        else sort_network<8>(e);
+        if (CAP > 16 && __ballot(cnt > 16u) != 0ull) { packed_sort<16>(d); Hcur = 16u; }
+        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) { packed_sort<8>(d); Hcur = 8u; }
+        else { packed_sort<4>(d); Hcur = 4u; }
     }
     // slots in use in the wave's fullest row: the toggle loop visits no more
     const uint32_t maxcnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(min(cnt, (uint32_t)CAP)), 63);
@@ -578,19 +603,32 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 // Unused slots step by 0; an over-full row (redone by fixup_kernel) never reaches 0.
                 int run = ovf ? 0x40000000 : 0;
                 bool zero = !ovf;
-#pragma unroll
-                for (int i = CAP - 1; i >= 0; --i) {
-                    if (i >= (int)maxcnt) continue;                             // wave-uniform
-                    run += (int)(e[i] & 3u) - 1;
+                auto slot = [&](uint32_t ei) {              // ei: (J << 2) | code in the low 16 bits
+                    run += (int)(ei & 3u) - 1;
                     const bool z = run == 0;
                     if (z != zero) {
-                        const uint32_t tm1 = (e[i] >> 2) - 1u;                  // toggle column - 1, 0 .. ncol-1
+                        const uint32_t tm1 = ((ei >> 2) & 0x3fffu) - 1u;        // toggle column - 1, 0 .. ncol-1
                         const uint32_t wv = tm1 >> WSHIFT;
                         // columns [0, t) of the window: (tm1 mod WCOLS) + 1 low bits
                         atomicXor(line + wv, ~0ull >> (63u - (tm1 & (uint32_t)(WCOLS - 1))));
                         fill ^= (1u << wv) - 1u;                                // every window to the left flips
                     }
                     zero = z;
+                };
+                // descending: the high halves hold slots Hcur .. 2 Hcur - 1, the low halves 0 .. Hcur - 1.
+                // Registers are visited four at a time — one scalar test per group; a slot past the
+                // wave's fullest row is unused and steps by 0.
+#pragma unroll
+                for (int g = CAP / 8 - 1; g >= 0; --g) {
+                    if ((uint32_t)(4 * g) >= Hcur || Hcur + (uint32_t)(4 * g) >= maxcnt) continue;      // wave-uniform
+#pragma unroll
+                    for (int j = 4 * g + 3; j >= 4 * g; --j) slot(d[j] >> 16);
+                }
+#pragma unroll
+                for (int g = CAP / 8 - 1; g >= 0; --g) {
+                    if ((uint32_t)(4 * g) >= Hcur || (uint32_t)(4 * g) >= maxcnt) continue;             // wave-uniform
+#pragma unroll
+                    for (int j = 4 * g + 3; j >= 4 * g; --j) slot(d[j]);
                 }
                 s_fill[hrow] = fill;
             }
@@ -685,12 +723,20 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             if (mine_half) {
                 uint32_t *dst = s_row + hrow * CAP;
                 int run = 0;
+                auto slot = [&](uint32_t ei, uint32_t i) {
+                    ei &= 0xffffu;
+                    const bool have = ei != EMPTY;
+                    run += (int)(ei & 3u) - 1;
+                    dst[i] = have ? (((ei >> 2) << 16) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
+                };
+                // sorted slot i sits in d[i % Hcur], half i / Hcur; slots past 2 Hcur are unused
+                for (uint32_t i = 2u * Hcur; i < (uint32_t)CAP; ++i) dst[i] = 0xffff0000u;
 #pragma unroll
-                for (int i = CAP - 1; i >= 0; --i) {
-                    const bool have = e[i] != EMPTY;
-                    run += (int)(e[i] & 3u) - 1;
-                    dst[i] = have ? (((e[i] >> 2) << 16) | ((uint32_t)run & 0xffffu)) : 0xffff0000u;
-                }
+                for (int j = CAP / 2 - 1; j >= 0; --j)
+                    if ((uint32_t)j < Hcur) slot(d[j] >> 16, Hcur + (uint32_t)j);
+#pragma unroll
+                for (int j = CAP / 2 - 1; j >= 0; --j)
+                    if ((uint32_t)j < Hcur) slot(d[j], (uint32_t)j);
                 if (ovf) dst[0] = 0xffffffffu;                      // (b = 0xffff, v = -1) cannot occur otherwise
             }
             wave_lds_sync();
