@@ -67,7 +67,8 @@ __device__ __forceinline__ float sqrt_rn(float x)
 enum : uint32_t {
     REC_LINEAR = 1u,     // a == 0 branch
     REC_NEG_ROOT = 2u,   // t- = (B - sqrt(delta)) / a ; otherwise t+
-    REC_LIN_MINUS = 4u   // linear branch adds -1 (p0y < p2y, :55) ; otherwise +1
+    REC_LIN_MINUS = 4u,  // linear branch adds -1 (p0y < p2y, :55) ; otherwise +1 ...
+    REC_LIN_PLUS = 2u    // ... and then carries this bit too: (flags & 2) is the crossing's step code (fr_render.hip)
 };
 
 struct Job {   // == fr_job (include/fr_raster.h)

@@ -130,7 +130,7 @@ __device__ inline bool build_record(const int16_t *p, uint32_t root, Rec &r)
         if (root != 0u || p2y == p0y) return false;      // :50
         r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
         r.rden = 1.0f / r.c1;
-        r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
+        r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : REC_LIN_PLUS);   // :55
     } else {
         r.a = a; r.b = p0y - p1y; r.c1 = p1y * p1y; r.c2 = p0y * p2y;    // :58, :60
         r.rden = 1.0f / a;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
         empty = (root != 0u) || (p2y == p0y);            // :50
         r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
         r.rden = 1.0f / r.c1;
-        r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : 0u);   // :55
+        r.flags = REC_LINEAR | ((p0y < p2y) ? REC_LIN_MINUS : REC_LIN_PLUS);   // :55
     } else {
         r.a = a; r.b = b; r.c1 = p1y * p1y; r.c2 = p0y * p2y;        // :58, :60
         r.rden = 1.0f / a;

@@ -369,23 +369,29 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         uint32_t carry = 0;
         for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
             const uint32_t p = p0 + lane;
-            const uint32_t mk = (p < npairs) ? (uint32_t)s_pairs[p] : 0u;
+            // slots past npairs hold no marker (the buffer is zeroed per band): lanes past the end
+            // decode the last record and a row that may lie outside the band — they compute like the
+            // others (no divergence) and are kept from the table walk and the append by `live`
+            const uint32_t mk = (uint32_t)s_pairs[p];
             const uint32_t k1 = max(wave_incl_max(mk), carry);
             carry = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
 #if defined(FR_ABLATE) && (FR_ABLATE == 10 || FR_ABLATE == 21)
-            if (p < npairs && A.n_jobs == 0xffffffffu) {    // timing-only: pairs are collected, never evaluated
+            const bool live = p < npairs && A.n_jobs == 0xffffffffu;    // timing-only: pairs are collected, never evaluated
+            if (live) {
 #else
-            if (p < npairs) {
+            const bool live = p < npairs;
+            {
 #endif
                 const uint32_t kk = k1 - 1u;
-                const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]);
+                const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]) & 127u;     // (< 64 when live)
                 const Rec r = s_rec[kk];
                 const float cyr = s_cy[row];
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (r.flags & REC_LINEAR) != 0;
                 const float delta = cyr * r.a + r.c1 - r.c2;
                 const float sq = sqrt_rn(delta);                               // == sqrt(delta), fr_device.hpp
-                // B - sqrt == B + (-sqrt) bit for bit: the t- root flips the sign bit (REC_NEG_ROOT is bit 1)
+                // B - sqrt == B + (-sqrt) bit for bit: the t- root flips the sign bit (REC_NEG_ROOT is bit 1;
+                // a linear record may carry that bit as REC_LIN_PLUS — its sqs is not used)
                 const float sqs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sq) ^ ((r.flags & REC_NEG_ROOT) << 30));
                 const float numq = r.b + sqs, numl = cyr - r.b;
                 const float num = lin ? numl : numq;
@@ -394,7 +400,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 const bool accepted = (lin || !(delta < 0.0f)) && !(t < 0.0f || t >= 1.0f);
                 const float xx = (r.ax * t + r.bx) * t + r.p0x;
                 const float dy = r.a * t + (-r.b);
-                const bool minus = lin ? ((r.flags & REC_LIN_MINUS) != 0) : (dy > 0.0f);       // :55 / :68
+                // winding step code (2: +1, 0: -1): :55 for a line (kept in the flags), :68 for a root
+                const uint32_t code = lin ? (r.flags & REC_LIN_PLUS) : ((dy > 0.0f) ? 0u : 2u);
                 // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
                 // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
                 // map, confirm with one paired read, walk only if the guess is off
@@ -408,18 +415,19 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     const float c0 = s_cxp[J], c1 = s_cxp[J + 1];    // one ds_read2_b32
 #endif
                     const bool good = (c0 <= xx) & (xx < c1);        // '&': both loads issue together
-                    if (!good) {
+                    if (!good & live) {
                         while (s_cxp[J + 1] <= xx) ++J;          // +inf sentinel stops it at ncol
                         while (s_cxp[J] > xx) --J;               // -inf sentinel stops it at 0
                     }
                 }
 #if defined(FR_ABLATE) && FR_ABLATE == 12
-                if (accepted && J > 0 && A.n_jobs == 0xffffffffu) {  // timing-only: evaluated, never appended
+                if (live & accepted & (J > 0) && A.n_jobs == 0xffffffffu) {  // timing-only: evaluated, never appended
 #else
-                if (accepted && J > 0) {
+                if (live & accepted & (J > 0)) {
 #endif
                     const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
-                    if (pos < (uint32_t)CAP) s_lists[row * LSTRIDE + pos] = (uint16_t)(((uint32_t)J << 2) | (minus ? 0u : 2u));
+                    // a row's list has room for CAP slots + 8 of padding: slot 32 + is a dump nobody reads
+                    s_lists[__umul24(row, LSTRIDE) + min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
                 }
             }
         }
