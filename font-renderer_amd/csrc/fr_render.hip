@@ -357,7 +357,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     // pairs starts, 0 elsewhere; a max-scan over the slots recovers every pair's record
     auto zero_markers = [&]() {
         uint4 *mz = reinterpret_cast<uint4 *>(s_pairs);
-        for (uint32_t q = lane; q < PCAP / 8u; q += 64u) mz[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t q = 0; q < PCAP / 512u; ++q) mz[lane + 64u * q] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();                        // (also orders these 16-B stores before the 2-B marker stores)
     };
     zero_markers();
@@ -595,7 +596,12 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             // zero the half's masks cooperatively (consecutive 16-B stores: no bank conflicts)
             {
                 uint4 *z = reinterpret_cast<uint4 *>(wregion);
-                for (uint32_t q = lane; q < ((PROWS_S / 2u) << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
+                if (nwin_log == 4u) {           // 256-px strip: a fixed 8 (4) stores per lane, no loop
+#pragma unroll
+                    for (uint32_t q = 0; q < PROWS_S / 8u; ++q) z[lane + 64u * q] = make_uint4(0, 0, 0, 0);
+                } else {
+                    for (uint32_t q = lane; q < ((PROWS_S / 2u) << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
+                }
             }
             wave_lds_sync();
             // ---- phase 1b: my row's toggles -> window masks (LDS, XOR), fill parity
@@ -719,10 +725,13 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             const bool win_on = true;
 #endif
             if (wx * 16u < sw && win_on) {
-#ifdef FR_WIN_UNROLL
-#pragma unroll FR_WIN_UNROLL
-#endif
-                for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) popcount_window(yl, wx);
+                if (nwin_log == 4u && prows == 16u && N == 4) {
+                    // the common full case (256-px strip, 16 pixel rows): four windows per lane, no loop
+#pragma unroll
+                    for (uint32_t it = 0; it < 4u; ++it) popcount_window((lane >> 4) + 4u * it, wx);
+                } else {
+                    for (uint32_t yl = lane >> nwin_log; yl < prows; yl += (64u >> nwin_log)) popcount_window(yl, wx);
+                }
             }
             wave_lds_sync();                    // masks are re-zeroed by the next half / band
             STAMP(5);                           // phase 2: windows + stores
