@@ -90,6 +90,7 @@ struct fr_plan {
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
+    bool uniform = false;        // see fr_plan_create
     uint64_t pixels = 0, need_cols = 0, need_rows = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -361,6 +362,11 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     p->strip_w = sw;
     p->bands = max_h ? (max_h + band - 1) / band : 1;
     p->strips = max_w ? (max_w + sw - 1) / sw : 1;
+    // uniform: every strip of every job is full (w a multiple of the strip width) and every wave band is
+    // full (h a multiple of 64 / n pixel rows) — atlas cells; the render kernel has instances for it
+    p->uniform = n_jobs > 0;
+    for (uint32_t j = 0; j < n_jobs; ++j)
+        if (jobs[j].w == 0 || jobs[j].h == 0 || jobs[j].w % sw || jobs[j].h % band) { p->uniform = false; break; }
     if ((uint64_t)n_jobs * p->bands * p->strips > 0x7fffffffull) {
         delete p;
         return fail(FR_E_UNSUPPORTED, "batch needs more than 2^31 workgroups; split it");
@@ -402,6 +408,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.seg_p0 = plan->gs->d_seg_p0;
     // fused: the render kernel builds each glyph's records in LDS itself (<= 256 candidate roots)
     a.fused = (plan->ctx->fuse_prepare && plan->gs->max_seg_per_glyph <= 128u) ? 1u : 0u;
+    a.uniform = plan->uniform ? 1u : 0u;
     a.out = out_dev;
     a.out_stride = out_stride;
     a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;

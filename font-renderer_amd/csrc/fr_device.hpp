@@ -88,6 +88,7 @@ struct RenderArgs {
     const int16_t *pts;                // glyph points / per-segment p0 index: the render kernel builds its
     const uint32_t *seg_p0;            // glyph's records itself (in LDS) when `fused` is set
     uint32_t fused;
+    uint32_t uniform;                  // every job: w a multiple of strip_w, h a multiple of the wave band (64/n rows)
     void *out;
     unsigned long long *ovf_bits;      // [n_jobs][bands][strips]: over-full sample rows of each wave band
     uint32_t *ovf_count;               // number of wave bands with any; ping-pong pair: this render counts in

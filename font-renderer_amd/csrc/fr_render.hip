@@ -186,12 +186,16 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int MODE, int N, int CAP>
 // three workgroups fit a CU's LDS: hold the register allocation to three waves per SIMD (<= 168 VGPRs)
 #ifndef FR_WAVES_PER_EU
 #define FR_WAVES_PER_EU 3
 #endif
 #define FR_OCC __attribute__((amdgpu_waves_per_eu(FR_WAVES_PER_EU, FR_WAVES_PER_EU)))
+// WLOG >= 0: "uniform" plan — every strip of every job is exactly 16 << WLOG pixels wide and every
+// job's height is a multiple of the wave band (RenderArgs::uniform, checked by fr_plan_create): strip
+// width, window count and rows per band are compile-time constants (loop counts, addresses, no edge
+// cases).  WLOG < 0: the general kernel.
+template <int MODE, int N, int CAP, int WLOG>
 __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const RenderArgs A)
 {
     constexpr uint32_t WBAND = 64u / N;         // pixel rows per wave band (64 sample rows)
@@ -216,10 +220,11 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     if (blockIdx.x == 0 && tid == 0) *A.ovf_count_next = 0u;     // (saves a memset node per render)
     if (band_first * WBAND >= job.h || x0s >= job.w) return;    // workgroup-uniform
     const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + WBAND - 1u) / WBAND);
-    const uint32_t sw = min(A.strip_w, job.w - x0s);            // strip width, pixels
+    constexpr bool UNI = WLOG >= 0;
+    const uint32_t sw = UNI ? (16u << (UNI ? WLOG : 0)) : min(A.strip_w, job.w - x0s);     // strip width, pixels
     const uint32_t ncol = sw * N;                               // sample columns in the strip
     const int phase = A.phase_center;
-    const uint32_t nwin_log = A.nwin_log;                       // windows per row, padded to 2^k
+    const uint32_t nwin_log = UNI ? (uint32_t)(UNI ? WLOG : 0) : A.nwin_log;   // windows per row, padded to 2^k
     const uint32_t nwin_pad = 1u << nwin_log;
 
     const uint32_t g = job.glyph;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const uint32_t band = band0 + wave;
     const bool band_valid = band < band_end;
     const uint32_t y0 = band * WBAND;
-    const uint32_t nrows = band_valid ? min(WBAND, job.h - y0) * N : 0u;    // sample rows of my band
+    const uint32_t nrows = band_valid ? (UNI ? 64u : min(WBAND, job.h - y0) * N) : 0u;    // sample rows of my band
 
     // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
     const bool row_valid = lane < nrows;
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         const bool mine_half = (PARTS == 1u) || ((lane >> 5) == half);
         const uint32_t hrow = lane & (PROWS_S - 1u);                // my row inside the part
         const uint32_t prow0 = y0 + half * HROWS;                   // first pixel row of the half
-        const uint32_t prows = min(HROWS, job.h - prow0);           // pixel rows in the half
+        const uint32_t prows = UNI ? HROWS : min(HROWS, job.h - prow0);   // pixel rows in the half
         const size_t out_row0 = (size_t)job.out_y + prow0;
         if (COV) {
             // zero the half's masks cooperatively (consecutive 16-B stores: no bank conflicts)
@@ -898,13 +903,13 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     *total = t + NW * TAIL_BYTES;
 }
 
-template <int MODE, int N, int CAP>
+template <int MODE, int N, int CAP, int WLOG>
 static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 {
     size_t lds;
     render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_rec_bytes, &a.lds_wave_bytes, &a.lds_tail, &lds);
     lds += a.lds_pad;
-    auto kern = render_kernel<MODE, N, CAP>;
+    auto kern = render_kernel<MODE, N, CAP, WLOG>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -919,12 +924,12 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int MODE, int N>
+template <int MODE, int N, int WLOG>
 static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
 {
-    if (a.kmax <= 8) return launch_one<MODE, N, 8>(a, grid, stream);
-    if (a.kmax <= 16) return launch_one<MODE, N, 16>(a, grid, stream);
-    return launch_one<MODE, N, 32>(a, grid, stream);
+    if (a.kmax <= 8) return launch_one<MODE, N, 8, WLOG>(a, grid, stream);
+    if (a.kmax <= 16) return launch_one<MODE, N, 16, WLOG>(a, grid, stream);
+    return launch_one<MODE, N, 32, WLOG>(a, grid, stream);
 }
 
 uint32_t render_wg_waves() { return NW; }
@@ -934,15 +939,20 @@ hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t strea
     const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
     if (a.strip_w == 0 || a.strip_w > 256u || (a.strip_w & 15u)) return hipErrorInvalidValue;
     if (mode == MODE_COVERAGE_U8) {
-        if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1>(a, grid, stream);
-        if (n == 2) return launch_cap<MODE_COVERAGE_U8, 2>(a, grid, stream);
-        if (n == 4) return launch_cap<MODE_COVERAGE_U8, 4>(a, grid, stream);
+        if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream);
+        if (n == 2) return launch_cap<MODE_COVERAGE_U8, 2, -1>(a, grid, stream);
+        if (n == 4) {
+            // uniform plans of 256- / 128-pixel strips (atlas cells) take the specialised instances
+            if (a.uniform && a.strip_w == 256u) return launch_cap<MODE_COVERAGE_U8, 4, 4>(a, grid, stream);
+            if (a.uniform && a.strip_w == 128u) return launch_cap<MODE_COVERAGE_U8, 4, 3>(a, grid, stream);
+            return launch_cap<MODE_COVERAGE_U8, 4, -1>(a, grid, stream);
+        }
         return hipErrorInvalidValue;
     }
     if (n != 1) return hipErrorInvalidValue;
-    if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1>(a, grid, stream);
-    if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1>(a, grid, stream);
-    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_MASK_NONZERO, 1>(a, grid, stream);
+    if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1, -1>(a, grid, stream);
+    if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1, -1>(a, grid, stream);
+    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_MASK_NONZERO, 1, -1>(a, grid, stream);
     return hipErrorInvalidValue;
 }
 
