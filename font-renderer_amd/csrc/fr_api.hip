@@ -376,6 +376,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(&p->d_ovf_bits, ((size_t)n_jobs * p->bands * p->strips + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_ovf_bits, 0, ((size_t)n_jobs * p->bands * p->strips + 1) * 8, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(&p->d_ovf_count, 16);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_ovf_count, 0, 16, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

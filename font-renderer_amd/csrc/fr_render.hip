@@ -210,10 +210,11 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     STAMP_INIT();
-    uint32_t bid = blockIdx.x;
-    const uint32_t strip = bid % A.strips; bid /= A.strips;
-    const uint32_t bgrp = bid % A.band_groups;
-    const uint32_t jidx = bid / A.band_groups;
+    // workgroup -> (job, band group, strip); one workgroup per cell is the common case (no divisions)
+    uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
+    if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
+    if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
+    const uint32_t jidx = bid;
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * A.strip_w;
     const uint32_t band_first = bgrp * A.bands_per_wg;          // in wave bands
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     // guess for J from the affine map, fixed up against the exact table
     const float jscale = job.scale * (float)N;
     const float joff = (float)min_xs * (float)N + (phase ? 0.5f : 0.0f) - 1.0f;
+    const float ncolf = (float)ncol;
     const size_t out_col0 = (size_t)job.out_x + x0s;
     __syncthreads();                            // the ONLY workgroup barrier for glyphs of <= 256 records
     // a glyph whose records fit one LDS chunk (all but pathological ones): every lane keeps the row
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 // J = #{ j in [0, ncol) : cx(j) <= xx }  ==  #{ j : not (xx < cx(j)) }   (:54,:66)
                 // <=> s_cxp[J] <= xx < s_cxp[J + 1] in the padded table; guess from the affine
                 // map, confirm with one paired read, walk only if the guess is off
-                float gf = xx * jscale - joff;
-                gf = fminf(fmaxf(gf, 0.0f), (float)ncol);
+                // (the guess is not reference arithmetic: one FMA and one median)
+                const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
                 int J = (int)gf;
                 {
 #if defined(FR_ABLATE) && FR_ABLATE == 11
@@ -524,7 +526,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     if (__ballot(cnt != 0u) == 0ull) {
         // ---- no crossing on any of my 64 sample rows: every winding is 0 — store the band's
         // background directly (cell padding, rows above/below the outline); no lists, no masks
-        if (lane == 0) A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = 0ull;
         const uint32_t bg = (MODE == MODE_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0*20+100) = 100 (:28)
         const uint32_t prows_b = nrows / N;
         const uint32_t wx = lane & (nwin_pad - 1u);
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     // ---- pull my list into registers and sort it by J (network size = the wave's fullest row)
     const bool ovf = cnt > (uint32_t)CAP;
     uint32_t d[16];                             // two slots per register
-    uint32_t Hcur;                              // registers in use: sorted slot i sits in d[i % Hcur], half i / Hcur
+    uint32_t Hcur, maxcnt;                      // registers in use: sorted slot i sits in d[i % Hcur], half i / Hcur
     {
         const uint4 *f = reinterpret_cast<const uint4 *>(mylist);
 #pragma unroll
@@ -570,22 +571,30 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = f[q];
             d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
         }
-        if (CAP > 16 && __ballot(cnt > 16u) != 0ull) { packed_sort<16>(d); Hcur = 16u; }
-        else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) { packed_sort<8>(d); Hcur = 8u; }
-        else { packed_sort<4>(d); Hcur = 4u; }
+        // maxcnt: slots in use in the wave's fullest row, rounded up to the toggle loop's step of 4
+        if (CAP > 16 && __ballot(cnt > 16u) != 0ull) {
+            packed_sort<16>(d); Hcur = 16u;
+            maxcnt = __ballot(cnt > 28u) ? 32u : (__ballot(cnt > 24u) ? 28u : (__ballot(cnt > 20u) ? 24u : 20u));
+        } else if (CAP > 8 && __ballot(cnt > 8u) != 0ull) {
+            packed_sort<8>(d); Hcur = 8u;
+            maxcnt = __ballot(cnt > 12u) ? 16u : 12u;
+        } else {
+            packed_sort<4>(d); Hcur = 4u;
+            maxcnt = __ballot(cnt > 4u) ? 8u : 4u;
+        }
     }
-    // slots in use in the wave's fullest row: the toggle loop visits no more
-    const uint32_t maxcnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(min(cnt, (uint32_t)CAP)), 63);
     COUNT(10, (unsigned long long)(maxcnt <= 8u) | ((unsigned long long)(maxcnt > 8u && maxcnt <= 12u) << 16) |
                   ((unsigned long long)(maxcnt > 12u && maxcnt <= 16u) << 32) | ((unsigned long long)(maxcnt > 16u) << 48));
     wave_lds_sync();                            // the list region becomes the mask region below
     STAMP(3);                                   // list pull + sort
     // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
-    // publish which of my 64 sample rows they are (one word per wave band, always written)
+    // publish which of my 64 sample rows they are (one word per wave band, written only if any)
     {
         const unsigned long long ovf_rows = __ballot(ovf);
-        if (lane == 0) A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
-        if (ovf_rows && lane == 0) atomicAdd(A.ovf_count, 1u);
+        if (ovf_rows && lane == 0) {            // (the words are zero otherwise: fixup_kernel clears what it used)
+            A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
+            atomicAdd(A.ovf_count, 1u);
+        }
     }
 
     // ---- phases 1b + 2, one half band (32 sample rows) at a time, wave-private LDS
@@ -881,6 +890,9 @@ __global__ __launch_bounds__(256) void fixup_kernel(const RenderArgs A)
                 else reinterpret_cast<uint8_t *>(A.out)[eidx] = (uint8_t)((2 * 255 * inside + N * N) / (2 * N * N));
             }
         }
+        // render_kernel writes a word only when it has a bit to set: hand it back clean
+        __syncthreads();
+        if (threadIdx.x == 0) A.ovf_bits[wd] = 0ull;
     }
 }
 
