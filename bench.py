@@ -34,8 +34,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3_cjk21k_256px_s128_16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--glyphs", type=int, default=0, help="override glyph count (smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

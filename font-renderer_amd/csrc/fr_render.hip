@@ -587,14 +587,14 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                   ((unsigned long long)(maxcnt > 12u && maxcnt <= 16u) << 32) | ((unsigned long long)(maxcnt > 16u) << 48));
     wave_lds_sync();                            // the list region becomes the mask region below
     STAMP(3);                                   // list pull + sort
-    // rows with more than CAP crossings are redone by fixup_kernel (direct sum, same integers):
-    // publish which of my 64 sample rows they are (one word per wave band, written only if any)
-    {
-        const unsigned long long ovf_rows = __ballot(ovf);
-        if (ovf_rows && lane == 0) {            // (the words are zero otherwise: fixup_kernel clears what it used)
-            A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
-            atomicAdd(A.ovf_count, 1u);
-        }
+    // rows with more than CAP crossings (combs, pathological outlines) take the direct sum over the
+    // glyph's records — same integers, slow, rare.  Coverage modes do it right here on the row's window
+    // masks (direct_rows below); the winding-value modes publish which of my 64 sample rows they are
+    // (one word per wave band, written only if any) for fixup_kernel.
+    const unsigned long long ovf_rows = __ballot(ovf);
+    if (!COV && ovf_rows && lane == 0) {        // (the words are zero otherwise: fixup_kernel clears what it used)
+        A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
+        atomicAdd(A.ovf_count, 1u);
     }
 
     // ---- phases 1b + 2, one half band (32 sample rows) at a time, wave-private LDS
@@ -661,7 +661,60 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 s_fill[hrow] = fill;
             }
             wave_lds_sync();
-            STAMP(4);                           // phase 1b: zero + toggles
+            if (ovf_rows) {
+                // ---- over-full sample rows: the toggle loop left their mask lines zero.  For each such
+                // row, every record of the glyph (the stand-alone records in HBM: all of them, whatever
+                // sits in LDS) is evaluated once — lane = record, 64 at a time — and broadcast with
+                // v_readlane to all lanes, each of which keeps the winding of 16 sample columns (lane L:
+                // columns 16 L ...).  Non-zero windings become the row's mask bits; its fill parity is 0.
+                const uint32_t n_all = A.glyph_rec_count[g];
+                const uint32_t col0 = 16u * lane;
+                unsigned long long todo_rows = (PARTS == 1u) ? ovf_rows : (ovf_rows >> (half * PROWS_S)) & (~0ull >> (64u - PROWS_S));
+                while (todo_rows) {
+                    const uint32_t r = (uint32_t)__builtin_ctzll(todo_rows);        // row inside the part
+                    todo_rows &= todo_rows - 1ull;
+                    const float cy_r = bcast(cy, half * PROWS_S + r);
+                    int w16[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) w16[c] = 0;
+                    for (uint32_t kb = 0; kb < n_all; kb += 64u) {
+                        const uint32_t k = kb + lane;
+                        bool ok = false;
+                        int J = 0, sgn = 0;
+                        if (k < n_all) {
+                            const Rec rk = grec[k];
+                            float xx;
+                            ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
+                            if (ok) {       // J = #{ j : cx(j) <= xx }, as in the evaluation pass
+                                J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                                while (s_cxp[J + 1] <= xx) ++J;
+                                while (s_cxp[J] > xx) --J;
+                            }
+                        }
+                        unsigned long long m = __ballot(ok && J > 0);
+                        while (m) {
+                            const int i = (int)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const uint32_t sJ = (uint32_t)__builtin_amdgcn_readlane(J, i);
+                            const int ss = __builtin_amdgcn_readlane(sgn, i);
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) w16[c] += (col0 + (uint32_t)c < sJ) ? ss : 0;
+                        }
+                    }
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) bits |= (w16[c] != 0 ? 1u : 0u) << c;
+                    // N lanes share a window word of 16 N columns: OR their 16-bit parts together
+                    const uint32_t q = lane % (uint32_t)N;
+                    uint32_t lo = (q < 2u) ? bits << (16u * q) : 0u, hi = (q >= 2u) ? bits << (16u * (q - 2u)) : 0u;
+                    if (N >= 2) { lo |= (uint32_t)__shfl_xor((int)lo, 1); hi |= (uint32_t)__shfl_xor((int)hi, 1); }
+                    if (N == 4) { lo |= (uint32_t)__shfl_xor((int)lo, 2); hi |= (uint32_t)__shfl_xor((int)hi, 2); }
+                    if (q == 0u && col0 < ncol)
+                        s_mask[(mask_line(r) << nwin_log) + lane / (uint32_t)N] = ((unsigned long long)hi << 32) | lo;
+                }
+                wave_lds_sync();
+            }
+            STAMP(4);                           // phase 1b: zero + toggles (+ over-full rows)
 
             // ---- phase 2: one lane per 16-pixel window
             // window (yl, wx) = pixels [16 wx, 16 wx + 16) of the half's pixel row yl.  Whether 16-byte
@@ -930,6 +983,7 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (MODE == MODE_COVERAGE_U8) return hipSuccess;    // over-full rows are settled inside render_kernel
     const size_t nwords = (size_t)a.n_jobs * a.bands * a.strips;
     const uint32_t fgrid = (uint32_t)(nwords < 4096 ? (nwords ? nwords : 1) : 4096);
     hipLaunchKernelGGL((fixup_kernel<MODE, N>), dim3(fgrid), dim3(256), 0, stream, a);
