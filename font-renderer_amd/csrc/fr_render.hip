@@ -374,15 +374,12 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         wave_lds_sync();
         STAMP(1);                               // pair layout
         COUNT(9, npairs);
-        uint32_t carry = 0;
-        for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
-            const uint32_t p = p0 + lane;
-            // slots past npairs hold no marker (the buffer is zeroed per band): lanes past the end
-            // decode the last record and a row that may lie outside the band — they compute like the
-            // others (no divergence) and are kept from the table walk and the append by `live`
-            const uint32_t mk = (uint32_t)s_pairs[p];
-            const uint32_t k1 = max(wave_incl_max(mk), carry);
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
+        // one pair per lane: evaluate, find its sample column, append to its row's list.  `k1` = the
+        // pair's record + 1 (from the marker scan).  Slots past npairs hold no marker (the buffer is
+        // zeroed per band): lanes past the end decode the last record and a row that may lie outside
+        // the band — they compute like the others (no divergence) and are kept from the table walk and
+        // the append by `live`.
+        auto eval_one = [&](uint32_t p, uint32_t k1) {
 #if defined(FR_ABLATE) && (FR_ABLATE == 10 || FR_ABLATE == 21)
             const bool live = p < npairs && A.n_jobs == 0xffffffffu;    // timing-only: pairs are collected, never evaluated
             if (live) {
@@ -438,6 +435,22 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     s_lists[__umul24(row, LSTRIDE) + min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
                 }
             }
+        };
+        // 128 pairs per trip: the two marker max-scans are independent chains (their DPP steps
+        // interleave instead of waiting out the DPP read-after-write gap), the second carries on from
+        // the first's last lane
+        uint32_t carry = 0;
+        for (uint32_t p0 = 0; p0 < npairs; p0 += 128u) {
+            const uint32_t pa = p0 + lane, pb = pa + 64u;
+            const bool two = p0 + 64u < npairs;                 // wave-uniform (PCAP is a multiple of 128: both reads stay inside)
+            const uint32_t ma = (uint32_t)s_pairs[pa], mb = (uint32_t)s_pairs[pb];
+            const uint32_t sa = wave_incl_max(ma), sb = wave_incl_max(mb);
+            const uint32_t ka = max(sa, carry);
+            const uint32_t cmid = (uint32_t)__builtin_amdgcn_readlane((int)ka, 63);
+            const uint32_t kb = max(sb, cmid);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)kb, 63);
+            eval_one(pa, ka);
+            if (two) eval_one(pb, kb);
         }
         wave_lds_sync();
         npairs = 0;
