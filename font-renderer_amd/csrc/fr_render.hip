@@ -436,21 +436,17 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 }
             }
         };
-        // 128 pairs per trip: the two marker max-scans are independent chains (their DPP steps
-        // interleave instead of waiting out the DPP read-after-write gap), the second carries on from
-        // the first's last lane
-        uint32_t carry = 0;
-        for (uint32_t p0 = 0; p0 < npairs; p0 += 128u) {
-            const uint32_t pa = p0 + lane, pb = pa + 64u;
-            const bool two = p0 + 64u < npairs;                 // wave-uniform (PCAP is a multiple of 128: both reads stay inside)
-            const uint32_t ma = (uint32_t)s_pairs[pa], mb = (uint32_t)s_pairs[pb];
-            const uint32_t sa = wave_incl_max(ma), sb = wave_incl_max(mb);
-            const uint32_t ka = max(sa, carry);
-            const uint32_t cmid = (uint32_t)__builtin_amdgcn_readlane((int)ka, 63);
-            const uint32_t kb = max(sb, cmid);
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)kb, 63);
-            eval_one(pa, ka);
-            if (two) eval_one(pb, kb);
+        // software pipeline: the marker max-scan of the NEXT 64 pairs is issued before the current 64
+        // are evaluated — an independent chain whose DPP steps interleave with the evaluation instead
+        // of waiting out the DPP read-after-write gap
+        uint32_t k_cur = wave_incl_max((uint32_t)s_pairs[lane]);
+        uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+        for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
+            const uint32_t pn = min(p0 + 64u + lane, PCAP - 1u);        // (past the buffer only when the loop ends)
+            const uint32_t s_next = wave_incl_max((uint32_t)s_pairs[pn]);
+            eval_one(p0 + lane, k_cur);
+            k_cur = max(s_next, carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
         }
         wave_lds_sync();
         npairs = 0;
