@@ -174,7 +174,16 @@ __device__ unsigned long long g_stamps[16];
 // LDS line of sample row r (0..31 of a half band) in a wave's window-mask array.  Swapping
 // line parity with bit 2 puts rows r and r+4 (the same sub-row of two adjacent pixel rows,
 // read together by one ds_read_b64 in phase 2) into different 128-B halves of the bank space.
+#ifdef FR_NO_SWIZZLE
+__device__ __forceinline__ uint32_t mask_line(uint32_t r) { return r; }
+#else
 __device__ __forceinline__ uint32_t mask_line(uint32_t r) { return r ^ ((r >> 2) & 1u); }
+#endif
+// 64-bit words of padding per mask line: with 0 every line starts in the same LDS bank and the toggles of a
+// vertical edge (64 rows, same window) all hit one bank pair; 1 staggers consecutive lines by two banks
+#ifndef FR_MASK_PAD
+#define FR_MASK_PAD 1
+#endif
 
 // LDS hand-off inside ONE wave (writer lanes -> reader lanes of the same wave): LDS operations
 // of a wave complete in order, so a drained lgkmcnt plus a compiler barrier is enough — no
@@ -227,6 +236,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const int phase = A.phase_center;
     const uint32_t nwin_log = UNI ? (uint32_t)(UNI ? WLOG : 0) : A.nwin_log;   // windows per row, padded to 2^k
     const uint32_t nwin_pad = 1u << nwin_log;
+    const uint32_t mrow = nwin_pad + FR_MASK_PAD;                // 64-bit words per mask line
 
     const uint32_t g = job.glyph;
     const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[g];
@@ -619,11 +629,13 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             // zero the half's masks cooperatively (consecutive 16-B stores: no bank conflicts)
             {
                 uint4 *z = reinterpret_cast<uint4 *>(wregion);
-                if (nwin_log == 4u) {           // 256-px strip: a fixed 8 (4) stores per lane, no loop
+                if (nwin_log == 4u) {           // 256-px strip: a fixed number of stores per lane, no loop
+                    constexpr uint32_t NZ = PROWS_S * (16u + FR_MASK_PAD) / 2u;    // 16-byte units
 #pragma unroll
-                    for (uint32_t q = 0; q < PROWS_S / 8u; ++q) z[lane + 64u * q] = make_uint4(0, 0, 0, 0);
+                    for (uint32_t q = 0; q < (NZ + 63u) / 64u; ++q)
+                        if (NZ % 64u == 0u || lane + 64u * q < NZ) z[lane + 64u * q] = make_uint4(0, 0, 0, 0);
                 } else {
-                    for (uint32_t q = lane; q < ((PROWS_S / 2u) << nwin_log); q += 64u) z[q] = make_uint4(0, 0, 0, 0);
+                    for (uint32_t q = lane; q < (PROWS_S * mrow + 1u) / 2u; q += 64u) z[q] = make_uint4(0, 0, 0, 0);
                 }
             }
             wave_lds_sync();
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #else
             if (mine_half) {
 #endif
-                unsigned long long *line = s_mask + (mask_line(hrow) << nwin_log);
+                unsigned long long *line = s_mask + mask_line(hrow) * mrow;
                 uint32_t fill = 0;
                 // right to left: `run` = winding right of the slots handled so far; a slot toggles
                 // inside/outside iff the winding changes between zero and non-zero across it.
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     if (N >= 2) { lo |= (uint32_t)__shfl_xor((int)lo, 1); hi |= (uint32_t)__shfl_xor((int)hi, 1); }
                     if (N == 4) { lo |= (uint32_t)__shfl_xor((int)lo, 2); hi |= (uint32_t)__shfl_xor((int)hi, 2); }
                     if (q == 0u && col0 < ncol)
-                        s_mask[(mask_line(r) << nwin_log) + lane / (uint32_t)N] = ((unsigned long long)hi << 32) | lo;
+                        s_mask[mask_line(r) * mrow + lane / (uint32_t)N] = ((unsigned long long)hi << 32) | lo;
                 }
                 wave_lds_sync();
             }
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #pragma unroll
                 for (int rr = 0; rr < N; ++rr) {
                     const uint32_t r = yl * N + rr;
-                    const unsigned long long mk = s_mask[(mask_line(r) << nwin_log) + wxx];
+                    const unsigned long long mk = s_mask[mask_line(r) * mrow + wxx];
                     // "windows left of a toggle are filled" parity of this window: 0 or all ones
                     const uint32_t fl = (uint32_t)__builtin_amdgcn_sbfe((int)s_fill[r], wxx, 1u);
                     mask[rr] = mk ^ (((unsigned long long)(fl & (uint32_t)(WALL >> 32)) << 32) | (fl & (uint32_t)WALL));
@@ -967,7 +979,7 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
     while ((1u << lg) < nwin) ++lg;
     const size_t cx = (((size_t)strip_w * n + 2) * 4 + 15) & ~(size_t)15;
     const size_t prow = 64u / FR_BAND_PARTS;
-    size_t wb = mode == MODE_COVERAGE_U8 ? prow * (8u << lg) : prow * cap * 4;
+    size_t wb = mode == MODE_COVERAGE_U8 ? ((prow * ((1u << lg) + FR_MASK_PAD) * 8u + 15u) & ~(size_t)15) : prow * cap * 4;
     const size_t walk = 64u * LSTRIDE * 2u + PCAP * 2u + 64u * 8u + RCHUNK * 2u;   // lists, pairs / markers, cy, counters, run offsets
     if (wb < walk) wb = walk;                                  // the walk's buffers live here first
     const size_t rb = (size_t)RCHUNK * sizeof(Rec);
