@@ -211,6 +211,28 @@ def test_zoomed_and_shrunk_cells(ctx, oracle, ascii_set):
         assert got.any()
 
 
+def test_uniform_plan_instances_equal_the_general_kernel(ctx, oracle):
+    """plans whose every job is a whole number of 256- / 128-pixel strips wide and of wave bands tall run
+    kernel instances with compile-time shapes; one odd-sized job in the batch sends the same cells through
+    the general instance — identical bytes, and both equal the oracle"""
+    for cell, segs in ((256, 96), (128, 40)):
+        gs = synth_glyphset(5, segs, first_index=3100 + cell)
+        jobs_u = cell_jobs(gs, cell, cell, 2048, 4)[:4]                      # uniform: 4 full cells
+        jobs_g = cell_jobs(gs, cell, cell, 2048, 5).copy()                   # + a fifth, 3 pixels short
+        jobs_g["w"][4] = cell - 3
+        jobs_g["h"][4] = cell - 3
+        dgs = fr.DeviceGlyphSet(ctx, gs)
+        a = np.zeros((cell, 4 * cell), np.uint8)
+        b = np.zeros((cell, 5 * cell), np.uint8)
+        rg.render_batch(dgs, jobs_u, fr.FR_COVERAGE_U8, a, 4, fr.FR_SAMPLE_CENTER)
+        rg.render_batch(dgs, jobs_g, fr.FR_COVERAGE_U8, b, 4, fr.FR_SAMPLE_CENTER)
+        dgs.close()
+        assert np.array_equal(a, b[:, :4 * cell]), cell
+        ref = np.zeros_like(b)
+        oracle.render_batch(gs, jobs_g, O.COVERAGE_U8, ref, 4, True, 8)
+        assert np.array_equal(b, ref), cell
+
+
 def test_exact_integer_path(ctx, oracle, ascii_set):
     """GlyphInfo.init + windingInGlyph (render_glyph.zig:76-300) incl. the GlyphDebug lattice"""
     oracle.diag_reset()
