@@ -741,7 +741,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             // window (yl, wx) = pixels [16 wx, 16 wx + 16) of the half's pixel row yl.  Whether 16-byte
             // stores apply is one wave-uniform fact (windows are 16 bytes apart) plus "the window is full".
             uint8_t *const out_half = reinterpret_cast<uint8_t *>(A.out) + out_row0 * A.out_stride + out_col0;
-            const bool aligned16 = ((reinterpret_cast<uintptr_t>(out_half) | (uintptr_t)A.out_stride) & 15u) == 0;
             auto store_window = [&](uint32_t yl, uint32_t wxx, const uint32_t (&pk)[4]) {
                 const uint32_t px = wxx * 16u;
                 uint8_t *dst = out_half + (size_t)yl * A.out_stride + px;
@@ -750,8 +749,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
 #else
-                if (aligned16 && sw - px >= 16u) {
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if (sw - px >= 16u) {
+                    // one 16-byte store, aligned or not (global memory takes unaligned vector stores)
+                    const uint4 v = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    __builtin_memcpy(dst, &v, 16);
                 } else {
                     const uint32_t nvalid = min(16u, sw - px);
                     for (uint32_t p = 0; p < nvalid; ++p) dst[p] = (uint8_t)(pk[p >> 2] >> (8 * (p & 3)));
