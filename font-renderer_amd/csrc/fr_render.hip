@@ -7,27 +7,28 @@
 //
 //   winding(cx, cy) = sum over accepted roots k of  sign_k * [ not (xx_k < cx) ]   (:54,:66)
 //
-// where (xx_k, sign_k) depend only on the segment and the ROW (cy).  Per workgroup =
-// (cell, band of 256/N pixel rows, column strip), 4 waves:
-//   phase 0  stage the glyph's root records whose exact acceptance interval [lo, hi]
-//            (fr_prepare.hip) meets the band into LDS — wave64 ballot + prefix-popcount
-//            compaction;
-//   phase 1  one lane per sample ROW.  Each wave pulls 64 staged records into registers
-//            (one per lane) and walks them with v_readlane broadcasts — no LDS round trip
-//            per record.  A lane whose cy lies in [lo, hi] evaluates t, xx, sign in the
-//            reference's own f32 operation order, converts xx into
-//            J = #{sample columns j : cx(j) <= xx} against an LDS table of the exact cx(j)
-//            (cx is monotone in j), and inserts (J, sign) into a small SORTED array kept
-//            in registers (min/max compare-exchange chain);
-//   phase 1b the lane suffix-sums its signs from the right: crossing i TOGGLES
-//            inside/outside iff the running winding changes between zero and non-zero
-//            across it.  Each toggle at column t XORs a prefix mask into the 64-bit LDS
-//            word of the 16-pixel window holding t (ds_xor_b64) and flips a per-row
-//            "windows to the left are filled" parity word — O(toggles) per row;
-//   phase 2  one lane per 16-pixel window: N mask words -> SWAR popcount per pixel ->
-//            16 output bytes, one coalesced 16-B store per lane (256 B per row run).
-// Per-pixel work is O(crossings of its row), not O(segments).  A row with more than CAP
-// crossings falls back to the direct sum over records (same integers, slower).
+// where (xx_k, sign_k) depend only on the segment and the ROW (cy).  Per workgroup = (cell, group of
+// wave bands, <= 256-px column strip), 4 waves; a wave band = 64 sample rows (64/N pixel rows):
+//   set-up   every thread builds one candidate root record of the glyph straight into LDS, with the
+//            EXACT range [ra, re) of this cell's sample rows on which the reference accepts it
+//            (fr_records.hpp: the acceptance test is monotone in cy); the padded table of the exact
+//            sample abscissae cx(j); ONE workgroup barrier.  Then the waves never meet again.
+//   layout   per band, each lane clips the ranges of its 4 records to the band; one DPP prefix sum
+//            places every record's run of (record, row) pairs in one sequence (marker at the run's
+//            first slot) — no loop over records.
+//   evaluate all 64 lanes take consecutive pairs (a DPP max-scan over the markers names the record):
+//            t, xx, sign in the reference's own f32 operation order and its three acceptance tests,
+//            J = #{sample columns j : cx(j) <= xx} against the table, append (J, step) to the row's
+//            list in LDS.
+//   sort     one lane per sample row: list -> registers (two 16-bit slots each), packed sorting network.
+//   toggles  right to left with the running winding: a slot that changes zero <-> non-zero XORs a prefix
+//            mask into the 64-bit LDS word of the 16-pixel window holding it (ds_xor_b64) and flips a
+//            per-row "windows to my left are filled" parity word — O(crossings) per row.
+//   windows  one lane per 16-pixel window: N mask words -> SWAR popcount per pixel -> 16 output bytes,
+//            one 16-B store per lane (256 B per row run).
+// Per-pixel work is O(crossings of its row), not O(segments).  A row with more than CAP crossings takes
+// the direct sum over records (same integers, slower): in-kernel for the coverage modes, fixup_kernel
+// for the winding-value modes.  DESIGN.md §3-§4 has the arguments and the measurements.
 #include "fr_records.hpp"
 
 namespace fr {
