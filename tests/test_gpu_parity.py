@@ -114,7 +114,7 @@ def test_overfull_rows_take_the_exact_fallback(ctx, oracle):
     try:
         for kmax in (32, 16, 8):
             ctx.set_option("kmax", kmax)
-            for mode, n in [(fr.FR_COVERAGE_U8, 4), (fr.FR_WINDING_I16, 1), (fr.FR_COVERAGE_U8, 2)]:
+            for mode, n in [(fr.FR_COVERAGE_U8, 4), (fr.FR_WINDING_I16, 1), (fr.FR_COVERAGE_U8, 2), (fr.FR_COVERAGE_U8, 1), (fr.FR_GRAY_DEBUG, 1)]:
                 got, ref = _batch_both(ctx, oracle, gs, jobs, mode, (192, 384), n, True)
                 assert np.array_equal(got, ref), (kmax, mode, n)
         ctx.set_option("kmax", 8)
