@@ -772,27 +772,34 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 }
                 uint32_t pk[4];
                 if (N == 4) {
-                    // SWAR per 32-bit half (8 pixels x 4 sample columns), the two halves never
-                    // exchange bits: pair counts, then the even / odd pairs of every nibble summed
-                    // over the 4 sample rows (<= 8 each), then even / odd pixels as bytes (<= 16)
+                    // per 32-bit half (8 pixels x 4 sample columns x 4 rows): a 4 x 4 BYTE transpose (two rounds
+                    // of v_perm_b32) turns the four rows' dwords into four dwords that each hold all 16
+                    // samples of two pixels — low nibbles one pixel, high nibbles the next; a masked
+                    // v_bcnt_u32_b32 counts a pixel; four counts are packed into a dword and mapped at once
 #pragma unroll
                     for (int hlf = 0; hlf < 2; ++hlf) {
-                        uint32_t pa = 0, pb = 0;
+                        const uint32_t x0 = (uint32_t)(mask[0] >> (32 * hlf)), x1 = (uint32_t)(mask[1] >> (32 * hlf));
+                        const uint32_t x2 = (uint32_t)(mask[2] >> (32 * hlf)), x3 = (uint32_t)(mask[3] >> (32 * hlf));
+                        const uint32_t a0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), a1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+                        const uint32_t b0 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), b1 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+                        uint32_t y[4];
+                        y[0] = __builtin_amdgcn_perm(b0, a0, 0x05040100u); y[1] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+                        y[2] = __builtin_amdgcn_perm(b1, a1, 0x05040100u); y[3] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+                        uint32_t k[8];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            uint32_t x = (uint32_t)(mask[rr] >> (32 * hlf));
-                            x = x - ((x >> 1) & 0x55555555u);
-                            pa += x & 0x33333333u;
-                            pb += (x >> 2) & 0x33333333u;
+                        for (int i = 0; i < 4; ++i) {
+                            k[2 * i] = (uint32_t)__popc(y[i] & 0x0f0f0f0fu);             // pixel 2i of the half
+                            k[2 * i + 1] = (uint32_t)__popc(y[i] & 0xf0f0f0f0u);         // pixel 2i + 1
                         }
-                        const uint32_t M = 0x0f0f0f0fu;
-                        const uint32_t ke = (pa & M) + (pb & M);                    // even pixels, 0..16
-                        const uint32_t ko = ((pa >> 4) & M) + ((pb >> 4) & M);      // odd pixels
-                        // round_half_up(255*k/16) = 16k - (k > 8), per byte
-                        const uint32_t ve = (ke << 4) - (((ke + 0x07070707u) >> 4) & 0x01010101u);
-                        const uint32_t vo = (ko << 4) - (((ko + 0x07070707u) >> 4) & 0x01010101u);
-                        pk[2 * hlf + 0] = __builtin_amdgcn_perm(vo, ve, 0x05010400u);
-                        pk[2 * hlf + 1] = __builtin_amdgcn_perm(vo, ve, 0x07030602u);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            // four counts -> four bytes: three byte permutes (selector 0x0c = a zero byte)
+                            const uint32_t lo2 = __builtin_amdgcn_perm(k[4 * q + 1], k[4 * q], 0x0c0c0400u);
+                            const uint32_t hi2 = __builtin_amdgcn_perm(k[4 * q + 3], k[4 * q + 2], 0x0c0c0400u);
+                            const uint32_t p4 = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
+                            // round_half_up(255*k/16) = 16k - (k > 8), per byte
+                            pk[2 * hlf + q] = (p4 << 4) - (((p4 + 0x07070707u) >> 4) & 0x01010101u);
+                        }
                     }
                 } else {
                     pk[0] = pk[1] = pk[2] = pk[3] = 0;
