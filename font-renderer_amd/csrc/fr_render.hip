@@ -400,7 +400,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #endif
                 const uint32_t kk = k1 - 1u;
                 const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]) & 127u;     // (< 64 when live)
-                const Rec r = s_rec[kk];
+                // (one 24-bit multiply-add for the record's address)
+                const Rec r = *reinterpret_cast<const Rec *>(reinterpret_cast<const unsigned char *>(s_rec - 1) + __umul24(k1, (uint32_t)sizeof(Rec)));
                 const float cyr = s_cy[row];
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
                 const bool lin = (r.flags & REC_LINEAR) != 0;
