@@ -220,7 +220,7 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
         const bool far_side = (root == 0u) == (a > 0.0f);            // this root satisfies (t - t_v) * 1 >= 0
         const bool tv_le0 = (b * a) <= 0.0f, tv_lt0 = (b * a) < 0.0f;     // a, b are integers: signs are exact
         const bool tv_ge1 = (a > 0.0f) ? (b >= a) : (b <= a);
-        const float yv = p0y - (b * b) / a;              // vertex height (a guess only)
+        const float yv = p0y - (b * b) * r.rden;         // vertex height (a guess only: no second division)
         if (far_side) {
             empty = tv_ge1;
             if (!tv_le0) c_start = yv;
