@@ -122,6 +122,12 @@ def test_overfull_rows_take_the_exact_fallback(ctx, oracle):
         sj = cell_jobs(sg, 80, 80, 2048, 3)
         got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_COVERAGE_U8, atlas_shape(6, 80, 3), 4, True)
         assert np.array_equal(got, ref)
+        # the same through the uniform-plan instances (128- and 256-pixel cells), many over-full rows
+        for cell, segs in ((128, 100), (256, 128)):
+            sg = synth_glyphset(3, segs, first_index=7000 + cell)
+            sj = cell_jobs(sg, cell, cell, 2048, 3)
+            got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_COVERAGE_U8, atlas_shape(3, cell, 3), 4, True)
+            assert np.array_equal(got, ref), cell
     finally:
         ctx.set_option("kmax", 32)
 
