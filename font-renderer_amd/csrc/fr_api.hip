@@ -84,9 +84,6 @@ struct fr_plan {
     fr_ctx *ctx = nullptr;
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
-    unsigned long long *d_ovf_bits = nullptr;
-    uint32_t *d_ovf_count = nullptr;    // two counters, used alternately
-    uint32_t render_parity = 0;
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
@@ -312,7 +309,7 @@ void fr_plan_destroy(fr_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    dfree(plan->d_jobs); dfree(plan->d_ovf_bits); dfree(plan->d_ovf_count);
+    dfree(plan->d_jobs);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
     delete plan;
@@ -375,10 +372,6 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&p->d_ovf_bits, ((size_t)n_jobs * p->bands * p->strips + 1) * 8);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_ovf_bits, 0, ((size_t)n_jobs * p->bands * p->strips + 1) * 8, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&p->d_ovf_count, 16);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_ovf_count, 0, 16, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -425,10 +418,6 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     while (bpw > nw && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + nw - 1u) / nw * nw;
     a.bands_per_wg = bpw;
     a.band_groups = (plan->bands + bpw - 1) / bpw;
-    a.ovf_bits = plan->d_ovf_bits;
-    a.ovf_count = plan->d_ovf_count + (plan->render_parity & 1u);
-    a.ovf_count_next = plan->d_ovf_count + ((plan->render_parity + 1u) & 1u);
-    plan->render_parity ^= 1u;
     HIP_TRY(hipSetDevice(plan->ctx->device));
     if (plan->params.mode == FR_SDF_U8) {
         HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));

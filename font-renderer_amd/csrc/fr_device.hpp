@@ -90,9 +90,6 @@ struct RenderArgs {
     uint32_t fused;
     uint32_t uniform;                  // every job: w a multiple of strip_w, h a multiple of the wave band (64/n rows)
     void *out;
-    unsigned long long *ovf_bits;      // [n_jobs][bands][strips]: over-full sample rows of each wave band
-    uint32_t *ovf_count;               // number of wave bands with any; ping-pong pair: this render counts in
-    uint32_t *ovf_count_next;          // ovf_count and zeroes ovf_count_next for the following render
     uint64_t out_stride;               // elements
     uint32_t n_jobs, bands, strips, strip_w, kmax;
     uint32_t bands_per_wg, band_groups;   // a workgroup walks bands_per_wg consecutive bands of its cell
@@ -153,7 +150,7 @@ __device__ __forceinline__ bool rec_cross(const Rec &r, float cy, float &xx, int
 }
 
 // direct sum over a glyph's records — the reference's own loop shape (render_glyph.zig:37-71):
-// used for over-full rows (fixup_kernel) and for the sign of the SDF
+// used for the sign of the SDF (the render kernel's over-full rows use rec_cross directly)
 __device__ inline int brute_winding(const Rec *__restrict__ recs, uint32_t n, float cx, float cy)
 {
     int w = 0;

@@ -1,5 +1,5 @@
 // fr_prepare.hip — stand-alone per-glyph-set precompute of the root records (fr_records.hpp).
-// Used at glyph-set creation (the records serve fixup_kernel and the SDF sign) and, per render,
+// Used at glyph-set creation (the records serve the render kernel's over-full rows and the SDF sign) and, per render,
 // for glyphs too large for the render kernel's in-LDS record build.
 #include "fr_records.hpp"
 

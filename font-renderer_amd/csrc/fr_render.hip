@@ -27,8 +27,8 @@
 //   windows  one lane per 16-pixel window: N mask words -> SWAR popcount per pixel -> 16 output bytes,
 //            one 16-B store per lane (256 B per row run).
 // Per-pixel work is O(crossings of its row), not O(segments).  A row with more than CAP crossings takes
-// the direct sum over records (same integers, slower): in-kernel for the coverage modes, fixup_kernel
-// for the winding-value modes.  DESIGN.md §3-§4 has the arguments and the measurements.
+// the direct sum over records (same integers, slower), inside the kernel.  DESIGN.md §3-§4 has the
+// arguments and the measurements.
 #include "fr_records.hpp"
 
 namespace fr {
@@ -228,7 +228,6 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * A.strip_w;
     const uint32_t band_first = bgrp * A.bands_per_wg;          // in wave bands
-    if (blockIdx.x == 0 && tid == 0) *A.ovf_count_next = 0u;     // (saves a memset node per render)
     if (band_first * WBAND >= job.h || x0s >= job.w) return;    // workgroup-uniform
     const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + WBAND - 1u) / WBAND);
     constexpr bool UNI = WLOG >= 0;
@@ -609,14 +608,43 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     wave_lds_sync();                            // the list region becomes the mask region below
     STAMP(3);                                   // list pull + sort
     // rows with more than CAP crossings (combs, pathological outlines) take the direct sum over the
-    // glyph's records — same integers, slow, rare.  Coverage modes do it right here on the row's window
-    // masks (direct_rows below); the winding-value modes publish which of my 64 sample rows they are
-    // (one word per wave band, written only if any) for fixup_kernel.
+    // glyph's records — same integers, slow, rare: the coverage modes write the row's window masks from it,
+    // the winding-value modes its pixels.
     const unsigned long long ovf_rows = __ballot(ovf);
-    if (!COV && ovf_rows && lane == 0) {        // (the words are zero otherwise: fixup_kernel clears what it used)
-        A.ovf_bits[((size_t)jidx * A.bands + band) * A.strips + strip] = ovf_rows;
-        atomicAdd(A.ovf_count, 1u);
-    }
+    // windings of sample row `br` of my band at the 16 sample columns 16 lane .. 16 lane + 15, by the direct
+    // sum: every record of the glyph (the stand-alone records in HBM: all of them, whatever sits in LDS) is
+    // evaluated once — lane = record, 64 at a time — and broadcast with v_readlane to all lanes
+    auto row_windings = [&](uint32_t br, int (&w16)[16]) {
+        const uint32_t n_all = A.glyph_rec_count[g];
+        const uint32_t col0 = 16u * lane;
+        const float cy_r = bcast(cy, br);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) w16[c] = 0;
+        for (uint32_t kb = 0; kb < n_all; kb += 64u) {
+            const uint32_t k = kb + lane;
+            bool ok = false;
+            int J = 0, sgn = 0;
+            if (k < n_all) {
+                const Rec rk = grec[k];
+                float xx;
+                ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
+                if (ok) {       // J = #{ j : cx(j) <= xx }, as in the evaluation pass
+                    J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                    while (s_cxp[J + 1] <= xx) ++J;
+                    while (s_cxp[J] > xx) --J;
+                }
+            }
+            unsigned long long m = __ballot(ok && J > 0);
+            while (m) {
+                const int i = (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t sJ = (uint32_t)__builtin_amdgcn_readlane(J, i);
+                const int ss = __builtin_amdgcn_readlane(sgn, i);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) w16[c] += (col0 + (uint32_t)c < sJ) ? ss : 0;
+            }
+        }
+    };
 
     // ---- phases 1b + 2, one half band (32 sample rows) at a time, wave-private LDS
 #pragma unroll
@@ -651,7 +679,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 uint32_t fill = 0;
                 // right to left: `run` = winding right of the slots handled so far; a slot toggles
                 // inside/outside iff the winding changes between zero and non-zero across it.
-                // Unused slots step by 0; an over-full row (redone by fixup_kernel) never reaches 0.
+                // Unused slots step by 0; an over-full row (settled by the direct sum below) never reaches 0.
                 int run = ovf ? 0x40000000 : 0;
                 bool zero = !ovf;
                 auto slot = [&](uint32_t ei) {              // ei: (J << 2) | code in the low 16 bits
@@ -690,40 +718,13 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 // sits in LDS) is evaluated once — lane = record, 64 at a time — and broadcast with
                 // v_readlane to all lanes, each of which keeps the winding of 16 sample columns (lane L:
                 // columns 16 L ...).  Non-zero windings become the row's mask bits; its fill parity is 0.
-                const uint32_t n_all = A.glyph_rec_count[g];
                 const uint32_t col0 = 16u * lane;
                 unsigned long long todo_rows = (PARTS == 1u) ? ovf_rows : (ovf_rows >> (half * PROWS_S)) & (~0ull >> (64u - PROWS_S));
                 while (todo_rows) {
                     const uint32_t r = (uint32_t)__builtin_ctzll(todo_rows);        // row inside the part
                     todo_rows &= todo_rows - 1ull;
-                    const float cy_r = bcast(cy, half * PROWS_S + r);
                     int w16[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) w16[c] = 0;
-                    for (uint32_t kb = 0; kb < n_all; kb += 64u) {
-                        const uint32_t k = kb + lane;
-                        bool ok = false;
-                        int J = 0, sgn = 0;
-                        if (k < n_all) {
-                            const Rec rk = grec[k];
-                            float xx;
-                            ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
-                            if (ok) {       // J = #{ j : cx(j) <= xx }, as in the evaluation pass
-                                J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                                while (s_cxp[J + 1] <= xx) ++J;
-                                while (s_cxp[J] > xx) --J;
-                            }
-                        }
-                        unsigned long long m = __ballot(ok && J > 0);
-                        while (m) {
-                            const int i = (int)__builtin_ctzll(m);
-                            m &= m - 1ull;
-                            const uint32_t sJ = (uint32_t)__builtin_amdgcn_readlane(J, i);
-                            const int ss = __builtin_amdgcn_readlane(sgn, i);
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) w16[c] += (col0 + (uint32_t)c < sJ) ? ss : 0;
-                        }
-                    }
+                    row_windings(half * PROWS_S + r, w16);
                     uint32_t bits = 0;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) bits |= (w16[c] != 0 ? 1u : 0u) << c;
@@ -865,9 +866,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #pragma unroll
                     for (int p = 0; p < 16; ++p) w[p] = 0;
                     const uint32_t *src = s_row + yl * CAP;
-                    if (src[0] == 0xffffffffu) {
-                        // over-full row: fixup_kernel rewrites it
-                    } else {
+                    if (src[0] == 0xffffffffu) continue;       // over-full row: written by the direct pass below
+                    {
                         int prev = 0;
                         for (int i = 0; i < CAP; ++i) {
                             const uint32_t en = src[i];
@@ -911,6 +911,21 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     }
                 }
             }
+            // over-full rows (skipped above): the direct sum, one pixel per sample column, stored from here
+            unsigned long long todo_rows = (PARTS == 1u) ? ovf_rows : (ovf_rows >> (half * PROWS_S)) & (~0ull >> (64u - PROWS_S));
+            while (todo_rows) {
+                const uint32_t r = (uint32_t)__builtin_ctzll(todo_rows);            // row inside the part (N == 1: a pixel row)
+                todo_rows &= todo_rows - 1ull;
+                int w16[16];
+                row_windings(half * PROWS_S + r, w16);
+                const size_t eidx = (out_row0 + r) * A.out_stride + out_col0 + 16u * lane;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (16u * lane + (uint32_t)c >= sw) continue;
+                    if (MODE == MODE_WINDING_I16) reinterpret_cast<int16_t *>(A.out)[eidx + c] = (int16_t)w16[c];
+                    else reinterpret_cast<uint8_t *>(A.out)[eidx + c] = (uint8_t)((MODE == MODE_GRAY_DEBUG) ? gray_debug(w16[c]) : (w16[c] != 0 ? 255u : 0u));
+                }
+            }
             wave_lds_sync();
         }
     }   // half band
@@ -929,56 +944,6 @@ extern "C" int fr_debug_read_stamps(unsigned long long *out16, int reset)
     return e == hipSuccess ? 0 : -2;
 }
 #endif
-
-// Over-full rows (more than CAP crossings on one sample row — combs, pathological outlines):
-// redo every pixel row that contains one by the direct sum over the glyph's records, the
-// reference's own loop shape (render_glyph.zig:37-71) restricted to accepted roots.  Launched
-// after render_kernel on the same stream; reads the per-wave-band words it published.  Slow,
-// exact, and almost always a no-op (one 8-byte load per wave band).
-template <int MODE, int N>
-__global__ __launch_bounds__(256) void fixup_kernel(const RenderArgs A)
-{
-    constexpr uint32_t WBAND = 64u / N;
-    if (*A.ovf_count == 0u) return;
-    const size_t nwords = (size_t)A.n_jobs * A.bands * A.strips;
-    for (size_t wd = blockIdx.x; wd < nwords; wd += gridDim.x) {
-        const uint32_t strip = (uint32_t)(wd % A.strips);
-        const uint32_t band = (uint32_t)((wd / A.strips) % A.bands);
-        const uint32_t jidx = (uint32_t)(wd / ((size_t)A.strips * A.bands));
-        const Job job = A.jobs[jidx];
-        const uint32_t y0 = band * WBAND, x0s = strip * A.strip_w;
-        if (y0 >= job.h || x0s >= job.w) continue;
-        const unsigned long long bits = A.ovf_bits[wd];
-        if (!bits) continue;
-        const uint32_t sw = min(A.strip_w, job.w - x0s);
-        const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[job.glyph];
-        const uint32_t rec_cnt = A.glyph_rec_count[job.glyph];
-        for (uint32_t pr = 0; pr < WBAND && y0 + pr < job.h; ++pr) {
-            if (!((bits >> (pr * N)) & ((1ull << N) - 1ull))) continue;     // no over-full sample row here
-            const uint32_t y = y0 + pr;
-            for (uint32_t x = threadIdx.x; x < sw; x += 256u) {
-                int inside = 0, w00 = 0;
-                for (int jj = 0; jj < N; ++jj) {
-                    const float cy = ((float)(job.max_y - (int32_t)y) - sub_off(jj, N, A.phase_center)) / job.scale;
-                    for (int ii = 0; ii < N; ++ii) {
-                        const float cx = ((float)(job.min_x + (int32_t)(x0s + x)) + sub_off(ii, N, A.phase_center)) / job.scale;
-                        const int wv = brute_winding(grec, rec_cnt, cx, cy);
-                        if (ii == 0 && jj == 0) w00 = wv;
-                        inside += (wv != 0);
-                    }
-                }
-                const size_t eidx = ((size_t)job.out_y + y) * A.out_stride + job.out_x + x0s + x;
-                if (MODE == MODE_WINDING_I16) reinterpret_cast<int16_t *>(A.out)[eidx] = (int16_t)w00;
-                else if (MODE == MODE_GRAY_DEBUG) reinterpret_cast<uint8_t *>(A.out)[eidx] = (uint8_t)gray_debug(w00);
-                else if (MODE == MODE_MASK_NONZERO) reinterpret_cast<uint8_t *>(A.out)[eidx] = w00 != 0 ? 255 : 0;
-                else reinterpret_cast<uint8_t *>(A.out)[eidx] = (uint8_t)((2 * 255 * inside + N * N) / (2 * N * N));
-            }
-        }
-        // render_kernel writes a word only when it has a bit to set: hand it back clean
-        __syncthreads();
-        if (threadIdx.x == 0) A.ovf_bits[wd] = 0ull;
-    }
-}
 
 // LDS plan: padded cx table | staged records [RCHUNK] | 4 x per-wave half-band region (window
 // masks [32][nwin_pad] u64, or breakpoint rows [32][CAP] u32) | 4 x fill[32]
@@ -1014,11 +979,7 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (MODE == MODE_COVERAGE_U8) return hipSuccess;    // over-full rows are settled inside render_kernel
-    const size_t nwords = (size_t)a.n_jobs * a.bands * a.strips;
-    const uint32_t fgrid = (uint32_t)(nwords < 4096 ? (nwords ? nwords : 1) : 4096);
-    hipLaunchKernelGGL((fixup_kernel<MODE, N>), dim3(fgrid), dim3(256), 0, stream, a);
-    return hipGetLastError();
+    return hipSuccess;                                  // (over-full rows are settled inside render_kernel)
 }
 
 template <int MODE, int N, int WLOG>
