@@ -1010,7 +1010,8 @@ hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t strea
     if (n != 1) return hipErrorInvalidValue;
     if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1, -1>(a, grid, stream);
     if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1, -1>(a, grid, stream);
-    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_MASK_NONZERO, 1, -1>(a, grid, stream);
+    // winding != 0 ? 255 : 0 is exactly the 1-sample coverage (round_half_up(255 k / 1), k in {0, 1})
+    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream);
     return hipErrorInvalidValue;
 }
 
