@@ -868,8 +868,13 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                     const uint32_t *src = s_row + yl * CAP;
                     if (src[0] == 0xffffffffu) continue;       // over-full row: written by the direct pass below
                     {
-                        int prev = 0;
-                        for (int i = 0; i < CAP; ++i) {
+                        // entries whose breakpoint lies at or left of my first column say nothing about my
+                        // 16 pixels: count them (cheap, wave-uniform trip count), then walk only the few
+                        // that reach into the window
+                        uint32_t i = 0;
+                        for (uint32_t q = 0; q < min(maxcnt, (uint32_t)CAP); ++q) i += ((int)(src[q] >> 16) <= j0) ? 1u : 0u;
+                        int prev = j0;
+                        while (i < (uint32_t)CAP) {
                             const uint32_t en = src[i];
                             const int bq = (int)(en >> 16);
                             const int v = (int)(int16_t)(en & 0xffffu);
@@ -879,7 +884,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                                 if (j >= prev && j < bq) w[p] = v;
                             }
                             prev = bq;
-                            if (bq == 0xffff) break;
+                            ++i;
+                            if (bq >= j0 + 16) break;           // (the unused slots hold breakpoint 0xffff, value 0)
                         }
                     }
                     const size_t eidx = (out_row0 + yl) * A.out_stride + out_col0 + px0;
