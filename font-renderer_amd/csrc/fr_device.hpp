@@ -29,7 +29,7 @@ struct __attribute__((aligned(16))) Rec {
     float lo, hi, a, b, c1, c2, ax, bx, p0x;
     uint32_t flags;
     float rden;          // RN(1 / d), d = the divisor of t: a (quadratic) or p2y - p0y (linear)
-    uint32_t pad1;
+    uint32_t sqsign;     // 0x80000000 for the t- root (XORed into sqrt(delta): B - sqrt == B + (-sqrt)), else 0
 };
 
 // x / d for an INTEGER divisor |d| <= 2^17 with rd = RN(1/d): Markstein's correction
@@ -65,7 +65,7 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r;
 }
 enum : uint32_t {
-    REC_LINEAR = 1u,     // a == 0 branch
+    REC_LINEAR = 0x80000000u,   // a == 0 branch (the sign bit: one signed compare tests it)
     REC_NEG_ROOT = 2u,   // t- = (B - sqrt(delta)) / a ; otherwise t+
     REC_LIN_MINUS = 4u,  // linear branch adds -1 (p0y < p2y, :55) ; otherwise +1 ...
     REC_LIN_PLUS = 2u    // ... and then carries this bit too: (flags & 2) is the crossing's step code (fr_render.hip)

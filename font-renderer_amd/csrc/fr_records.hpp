@@ -125,7 +125,7 @@ __device__ inline bool build_record(const int16_t *p, uint32_t root, Rec &r)
     r.ax = p0x - 2 * p1x + p2x;                          // :53/:65
     r.bx = 2 * (p1x - p0x);
     r.p0x = p0x;
-    r.pad1 = 0;
+    r.sqsign = root ? 0x80000000u : 0u;
     if (a == 0.0f) {                                     // :49
         if (root != 0u || p2y == p0y) return false;      // :50
         r.a = 0.0f; r.b = p0y; r.c1 = p2y - p0y; r.c2 = 0.0f;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
     r.ax = p0x - 2 * p1x + p2x;                          // :53/:65
     r.bx = 2 * (p1x - p0x);
     r.p0x = p0x;
-    r.pad1 = 0;
+    r.sqsign = root ? 0x80000000u : 0u;
     const bool lin = a == 0.0f;                          // :49
     const float b = p0y - p1y;
     // ends of the accepted set in exact arithmetic: `start` is where t = 0 (or the vertex), `stop`

@@ -403,12 +403,11 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
                 const Rec r = *reinterpret_cast<const Rec *>(reinterpret_cast<const unsigned char *>(s_rec - 1) + __umul24(k1, (uint32_t)sizeof(Rec)));
                 const float cyr = s_cy[row];
                 // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67)
-                const bool lin = (r.flags & REC_LINEAR) != 0;
+                const bool lin = (int32_t)r.flags < 0;                         // REC_LINEAR is the sign bit
                 const float delta = cyr * r.a + r.c1 - r.c2;
                 const float sq = sqrt_rn(delta);                               // == sqrt(delta), fr_device.hpp
-                // B - sqrt == B + (-sqrt) bit for bit: the t- root flips the sign bit (REC_NEG_ROOT is bit 1;
-                // a linear record may carry that bit as REC_LIN_PLUS — its sqs is not used)
-                const float sqs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sq) ^ ((r.flags & REC_NEG_ROOT) << 30));
+                // B - sqrt == B + (-sqrt) bit for bit: the t- root's record carries the sign bit to flip
+                const float sqs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, sq) ^ r.sqsign);
                 const float numq = r.b + sqs, numl = cyr - r.b;
                 const float num = lin ? numl : numq;
                 const float t = div_by_int(num, lin ? r.c1 : r.a, r.rden);     // == num / d, see fr_device.hpp
