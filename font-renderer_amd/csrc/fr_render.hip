@@ -398,7 +398,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             {
 #endif
                 const uint32_t kk = k1 - 1u;
-                const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]) & 127u;     // (< 64 when live)
+                // (< 64 when live; a lane past the end lands on a row index < 128: still inside s_cy | s_cnt)
+                const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[kk]);
                 // (one 24-bit multiply-add for the record's address)
                 const Rec r = *reinterpret_cast<const Rec *>(reinterpret_cast<const unsigned char *>(s_rec - 1) + __umul24(k1, (uint32_t)sizeof(Rec)));
                 const float cyr = s_cy[row];
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #endif
                     const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
                     // a row's list has room for CAP slots + 8 of padding: slot 32 + is a dump nobody reads
-                    s_lists[__umul24(row, LSTRIDE) + min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
+                    uint16_t *rowlist = s_lists + __umul24(row, LSTRIDE);
+                    rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
                 }
             }
         };
