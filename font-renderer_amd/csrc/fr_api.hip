@@ -78,12 +78,14 @@ struct fr_glyphset {
     int16_t *d_pts = nullptr;
     uint32_t *d_seg_p0 = nullptr, *d_seg_prev = nullptr, *d_glyph_seg_start = nullptr, *d_rec_count = nullptr;
     fr::Rec *d_recs = nullptr;
+    std::vector<uint32_t> h_glyph_seg_start;    // host copy: plans attach each job's segment range to it
 };
 
 struct fr_plan {
     fr_ctx *ctx = nullptr;
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
+    uint32_t *d_job_seg = nullptr;     // [n_jobs][2]: first segment and segment count of the job's glyph
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
@@ -262,6 +264,7 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
         GS_TRY(hipMemcpyAsync(gs->d_seg_prev, seg_prev.data(), (size_t)gs->n_seg * 4, hipMemcpyHostToDevice, st));
     }
     GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
+    gs->h_glyph_seg_start = gseg;
     GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
     fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, n_glyphs, gs->d_recs,
                        gs->d_rec_count, st);
@@ -309,7 +312,7 @@ void fr_plan_destroy(fr_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    dfree(plan->d_jobs);
+    dfree(plan->d_jobs); dfree(plan->d_job_seg);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
     delete plan;
@@ -372,6 +375,16 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
+    // each job's segment range, next to the job: the render kernel starts on the glyph's points without a
+    // dependent look-up through the glyph table
+    std::vector<uint32_t> jseg((size_t)n_jobs * 2);
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        jseg[2 * (size_t)j] = gs->h_glyph_seg_start[jobs[j].glyph];
+        jseg[2 * (size_t)j + 1] = gs->h_glyph_seg_start[jobs[j].glyph + 1] - gs->h_glyph_seg_start[jobs[j].glyph];
+    }
+    if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_job_seg, (size_t)n_jobs * 8);
+    if (e == hipSuccess && n_jobs)
+        e = hipMemcpyAsync(p->d_job_seg, jseg.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -396,6 +409,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     fr::RenderArgs a;
     a.jobs = plan->d_jobs;
     a.glyph_seg_start = plan->gs->d_glyph_seg_start;
+    a.job_seg = plan->d_job_seg;
     a.glyph_rec_count = plan->gs->d_rec_count;
     a.recs = plan->gs->d_recs;
     a.pts = plan->gs->d_pts;

@@ -83,6 +83,7 @@ struct Job {   // == fr_job (include/fr_raster.h)
 struct RenderArgs {
     const Job *jobs;
     const uint32_t *glyph_seg_start;   // record slice of glyph g starts at 2*glyph_seg_start[g]
+    const uint32_t *job_seg;           // [n_jobs][2]: glyph_seg_start[g] and the segment count of job j's glyph g
     const uint32_t *glyph_rec_count;
     const Rec *recs;
     const int16_t *pts;                // glyph points / per-segment p0 index: the render kernel builds its

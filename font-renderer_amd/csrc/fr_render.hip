@@ -239,9 +239,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const uint32_t mrow = nwin_pad + FR_MASK_PAD;                // 64-bit words per mask line
 
     const uint32_t g = job.glyph;
-    const Rec *grec = A.recs + 2u * (size_t)A.glyph_seg_start[g];
+    const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];   // (loaded with the job)
+    const Rec *grec = A.recs + 2u * (size_t)seg0;
     // fused: one slot per candidate root (2 per segment); else the compacted count of prepare_kernel
-    const uint32_t rec_cnt = A.fused ? 2u * (A.glyph_seg_start[g + 1] - A.glyph_seg_start[g]) : A.glyph_rec_count[g];
+    const uint32_t rec_cnt = A.fused ? 2u * nseg : A.glyph_rec_count[g];
 
     // LDS: padded cx table | staged records (<= 256, read-only while waves walk them) |
     //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         // tid>>1; plans are fused only when every glyph has <= 128 segments): no separate
         // prepare pass, no record traffic through HBM.  Slots of non-existent / provably empty
         // roots hold an empty interval and never pass a cull.
-        const uint32_t s0g = A.glyph_seg_start[g];
+        const uint32_t s0g = seg0;
         if (tid < rec_cnt) {
             Rec r;
             RowGeom geo;
