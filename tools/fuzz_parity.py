@@ -30,8 +30,14 @@ for case in range(cases):
     n = int(rng.choice([1, 2, 4])) if mode == 3 else 1
     center = bool(rng.integers(0, 2))
     rows, x = [], int(rng.integers(0, 20))
+    uniform = mode == 3 and n == 4 and rng.random() < 0.4      # atlas cells: the uniform-plan kernel instances
+    ucell = int(rng.choice([128, 256]))
+    if uniform:
+        x = 16 * int(rng.integers(0, 3))
     for g in range(len(gs)):
         w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+        if uniform:
+            w, h = ucell * int(rng.integers(1, 3)), 16 * int(rng.integers(1, 14))
         if mode == 4:
             w, h = min(w, 40), min(h, 40)
         fs = int(rng.integers(4, 400))
@@ -39,7 +45,7 @@ for case in range(cases):
         box = gs.boxes[g].astype(np.float32)
         rows.append((g, int(np.floor(box[0] * s)) + int(rng.integers(-6, 6)), int(np.ceil(box[3] * s)) + int(rng.integers(-6, 6)),
                      w, h, x, int(rng.integers(0, 5)), s))
-        x += w + int(rng.integers(0, 18))
+        x += w + (16 * int(rng.integers(0, 2)) if uniform else int(rng.integers(0, 18)))
     jobs = rg.make_jobs(rows)
     shape = (max(r[4] + r[6] for r in rows) + 2, x + 3)
     dt = np.int16 if mode == 0 else np.uint8
