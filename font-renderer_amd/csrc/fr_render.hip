@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (tot <= PCAP) {                      // (wave-uniform) else: the generic path below, with flushes
             uint32_t off = incl - csum;
+            uint32_t ro[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #if defined(FR_ABLATE) && FR_ABLATE == 8
@@ -491,12 +492,13 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
 #else
                 if (c[i]) {
 #endif
-                    const uint32_t k = 4u * lane + (uint32_t)i;
-                    s_pairs[off] = (uint16_t)(k + 1u);
-                    s_roff[k] = (int16_t)((int32_t)(r0[i] - row_b0) - (int32_t)off);
+                    s_pairs[off] = (uint16_t)(4u * lane + (uint32_t)i + 1u);
                 }
+                ro[i] = (r0[i] - row_b0 - off) & 0xffffu;           // row offset of the run (unused if the run is empty)
                 off += c[i];
             }
+            // my four records' offsets sit side by side: one 8-byte store
+            *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
             npairs = tot;
             if (npairs) eval_pairs();
             laid_out = true;
