@@ -433,15 +433,18 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.bands_per_wg = bpw;
     a.band_groups = (plan->bands + bpw - 1) / bpw;
     HIP_TRY(hipSetDevice(plan->ctx->device));
-    if (plan->params.mode == FR_SDF_U8) {
-        HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
-        return FR_OK;
-    }
     // a render always starts from the glyph POINTS: either inside the render kernel (fused) or by
     // re-running the stand-alone precompute first
     if (!a.fused)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->gs->n_glyphs,
                            plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
+    if (plan->params.mode == FR_SDF_U8) {
+        // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,
+        // same sample points) lands in the output; the distance kernel reads it and overwrites it
+        HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
+        HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
+        return FR_OK;
+    }
     HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
     return FR_OK;
 }

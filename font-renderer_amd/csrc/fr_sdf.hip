@@ -9,12 +9,17 @@
 //                t in [0,1], of |B(t) - q| (font units): 9 uniform probes, then 4 Newton steps on
 //                (B(t)-q).B'(t) = 0 clamped to the probe's neighbourhood; times `scale` -> pixels
 //   sign       : + inside (winding != 0, the reference's non-zero test on its own winding number,
-//                render_glyph.zig:29,35-73), - outside
+//                render_glyph.zig:29,35-73), - outside; taken from the byte render_kernel's 1-sample
+//                coverage left in the output (255 / 0) right before this kernel
 //   encoding   : u8 = clamp(floor(128 + 16*d + 0.5), 0, 255)   (8 pixels of range either side)
 //
 // Shape: one workgroup per 16x16-pixel tile of a cell, one lane per pixel; the glyph's control
 // points are staged through LDS as f32 (256 segments at a time) and read back as broadcasts.
-// Brute force, O(segments) per pixel: VALU-bound by design, not a bandwidth kernel.
+// The encoding saturates 8 pixels from the outline, so a segment whose control-point box (the curve
+// lies inside it) is farther than that from the whole tile cannot change any of the tile's bytes: it
+// is dropped while staging (LDS counter compaction; the minimum does not depend on the order).  The
+// distance the kernel computes is the distance to SOME point of the curve, hence >= the box distance:
+// every dropped segment would have produced a value past the clamp.
 #include "fr_device.hpp"
 
 namespace fr {
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
                                                   int phase_center)
 {
     __shared__ float s_seg[256][6];
+    __shared__ uint32_t s_n;
     uint32_t bid = blockIdx.x;
     const uint32_t tx = bid % tiles_x; bid /= tiles_x;
     const uint32_t ty = bid % tiles_y;
@@ -73,16 +79,34 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
     const float qx = ((float)(job.min_x + (int32_t)x) + off) / job.scale;       // render_glyph.zig:26
     const float qy = ((float)(job.max_y - (int32_t)y) - off) / job.scale;       // :27
     const uint32_t s0 = glyph_seg_start[job.glyph], s1 = glyph_seg_start[job.glyph + 1];
+    // the tile's sample points span [tqx0, tqx1] x [tqy0, tqy1] (font units; the maps are monotone)
+    const float tqx0 = ((float)(job.min_x + (int32_t)(tx * 16u)) + off) / job.scale;
+    const float tqx1 = ((float)(job.min_x + (int32_t)(tx * 16u + 15u)) + off) / job.scale;
+    const float tqy1 = ((float)(job.max_y - (int32_t)(ty * 16u)) - off) / job.scale;
+    const float tqy0 = ((float)(job.max_y - (int32_t)(ty * 16u + 15u)) - off) / job.scale;
+    // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding
+    const float reach = 8.0f / job.scale * 1.02f + 1.0f;
     float best = 3.402823466e+38f;
     for (uint32_t base = s0; base < s1; base += 256u) {
+        if (threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
         const uint32_t s = base + threadIdx.x;
         if (s < s1) {
             const int16_t *p = pts + 2u * (size_t)seg_p0[s];
+            float c[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s_seg[threadIdx.x][k] = (float)p[k];
+            for (int k = 0; k < 6; ++k) c[k] = (float)p[k];
+            const float hx0 = fminf(fminf(c[0], c[2]), c[4]), hx1 = fmaxf(fmaxf(c[0], c[2]), c[4]);
+            const float hy0 = fminf(fminf(c[1], c[3]), c[5]), hy1 = fmaxf(fmaxf(c[1], c[3]), c[5]);
+            const float gx = fmaxf(fmaxf(hx0 - tqx1, tqx0 - hx1), 0.0f), gy = fmaxf(fmaxf(hy0 - tqy1, tqy0 - hy1), 0.0f);
+            if (gx * gx + gy * gy <= reach * reach) {
+                const uint32_t slot = atomicAdd(&s_n, 1u);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s_seg[slot][k] = c[k];
+            }
         }
         __syncthreads();
-        const uint32_t n = min(256u, s1 - base);
+        const uint32_t n = s_n;
         if (valid)
             for (uint32_t k = 0; k < n; ++k) {
                 const float d2 = seg_dist2(s_seg[k][0], s_seg[k][1], s_seg[k][2], s_seg[k][3], s_seg[k][4], s_seg[k][5], qx, qy);
@@ -91,13 +115,14 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
         __syncthreads();
     }
     if (!valid) return;
-    const int w = brute_winding(recs + 2u * (size_t)s0, glyph_rec_count[job.glyph], qx, qy);
+    uint8_t *px = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
+    const bool inside = *px != 0;              // render_kernel<COVERAGE_U8, 1>: winding != 0 at this sample
     float d = (s1 > s0) ? __builtin_sqrtf(best) * job.scale : 3.402823466e+38f;
-    if (w == 0) d = -d;
+    if (!inside) d = -d;
     float v = 16.0f * d + 128.0f;
     v = floorf(v + 0.5f);
     v = fminf(fmaxf(v, 0.0f), 255.0f);
-    out[((size_t)job.out_y + y) * out_stride + job.out_x + x] = (uint8_t)v;
+    *px = (uint8_t)v;
 }
 
 hipError_t launch_sdf(const RenderArgs &a, const int16_t *pts, const uint32_t *seg_p0, uint32_t max_w,
