@@ -431,6 +431,13 @@ def test_sdf_matches_its_cpu_twin(ctx, oracle, ascii_set, center):
     sj = cell_jobs(sg, 96, 96, 2048, 3)
     got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_SDF_U8, atlas_shape(6, 96, 3), 1, center, threads=16)
     assert np.array_equal(got, ref)
+    # larger cells: most 16x16 tiles lie beyond the encoding's 8-pixel reach of most segments (the
+    # kernel drops those while staging) and many saturate outright
+    sg2 = synth_glyphset(2, 64, first_index=5100)
+    sj2 = cell_jobs(sg2, 224, 224, 2048, 2)
+    got2, ref2 = _batch_both(ctx, oracle, sg2, sj2, fr.FR_SDF_U8, atlas_shape(2, 224, 2), 1, center, threads=16)
+    assert np.array_equal(got2, ref2)
+    assert (got2 == 0).any() and (got2 == 255).any()
     # sign agrees with the coverage mask: inside -> >= 128, outside -> <= 128 (|d| < 1/32 px rounds to 128)
     mask = np.zeros_like(got)
     rg.render_batch(fr.DeviceGlyphSet(ctx, sg), sj, fr.FR_MASK_NONZERO, mask, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
