@@ -28,6 +28,8 @@ WORKLOADS = {
     "c2_ascii95_128px_s32_16spp": dict(glyphs=95, cell=128, segs=32, n=4, cols=16),
     # BASELINE.json configs[3] per-GPU share (BMP/8 = 7936 glyphs, 128^2, 16 samples)
     "c4_bmp_shard_128px_s32_16spp": dict(glyphs=7936, cell=128, segs=32, n=4, cols=64),
+    # BASELINE.json configs[4] per-GPU share (4 096 glyphs / 8 = 512, 512^2 cells): build-defined SDF, 1 sample
+    "c5_sdf_shard_512px_s64": dict(glyphs=512, cell=512, segs=64, n=1, cols=16, mode="sdf"),
 }
 
 
@@ -82,6 +84,7 @@ def main():
     if args.segs:
         wl["segs"] = args.segs
     G, cell, S, n, cols = wl["glyphs"], wl["cell"], wl["segs"], wl["n"], wl["cols"]
+    sdf = wl.get("mode") == "sdf"
 
     # ---- inputs: this rank's glyph range (weak scaling: G glyphs per GPU)
     t_gen = time.time()
@@ -99,7 +102,7 @@ def main():
         out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
     dgs = fr.DeviceGlyphSet(ctx, gs)                       # points -> HBM (+ first precompute)
     jobs = cell_jobs(gs, cell, cell, 2048, cols)
-    plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER)
+    plan = fr.Plan(dgs, jobs, fr.FR_SDF_U8 if sdf else fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER)
     pixels = plan.pixels
     stats = dgs.stats()
 
@@ -150,7 +153,8 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload if not args.glyphs else "", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "fr::render_kernel<COVERAGE_U8,4>", "achieved": round(achieved, 2),
+    roofline = {"bound": "hbm", "kernel": "fr::render_kernel<COVERAGE_U8,1> + fr::sdf_kernel" if sdf else f"fr::render_kernel<COVERAGE_U8,{n}>",
+                "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "algorithmic_bytes_per_launch": pixels, "kernel_ms": round(k_ms, 4),
                 "prepare_kernel_ms": round(prep_ms, 4)}
@@ -164,14 +168,15 @@ def main():
         probe = min(2, G)
         buf = np.zeros(atlas_shape(probe, cell, cols), np.uint8)
         t = time.perf_counter()
-        orc.render_batch(gs, jobs[:probe], oracle_lib.COVERAGE_U8, buf, n, True, 1)
+        omode = oracle_lib.SDF_U8 if sdf else oracle_lib.COVERAGE_U8
+        orc.render_batch(gs, jobs[:probe], omode, buf, n, True, 1)
         per_glyph = (time.perf_counter() - t) / probe
         ng = int(max(threads, min(G, args.cpu_seconds * threads / max(per_glyph, 1e-9))))
         unit = max(threads, cols)                      # whole atlas rows, so the sample can be compared with the GPU's bytes
         ng = min(G, (ng // unit) * unit if ng >= unit else ng)
         buf = np.zeros(atlas_shape(ng, cell, cols), np.uint8)
         t = time.perf_counter()
-        orc.render_batch(gs, jobs[:ng], oracle_lib.COVERAGE_U8, buf, n, True, threads)
+        orc.render_batch(gs, jobs[:ng], omode, buf, n, True, threads)
         ct = time.perf_counter() - t
         with torch.cuda.stream(stream):
             same = bool(np.array_equal(out[:buf.shape[0]].cpu().numpy(), buf)) if (ng % cols == 0 or ng <= cols) else None
@@ -188,7 +193,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "glyphs_per_gpu": G, "cell": f"{cell}x{cell}", "segments_per_glyph": S,
-                       "samples_per_pixel": n * n, "pixels_per_step_per_gpu": pixels,
+                       "samples_per_pixel": n * n, "mode": "sdf_u8" if sdf else "coverage_u8", "pixels_per_step_per_gpu": pixels,
                        "root_records": stats["records"], "step": "points -> atlas (records rebuilt every render)",
                        "parallelism": f"glyph-sharded x{world}, no collective"},
             "roofline": roofline, "cpu_baseline": cpu,
