@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
                                                   uint64_t out_stride, uint32_t tiles_x, uint32_t tiles_y,
                                                   int phase_center)
 {
-    __shared__ float s_seg[256][6];
+    __shared__ float s_seg[256][10];            // p0, p1, p2 and the control-point box (x0, x1, y0, y1)
     __shared__ uint32_t s_n;
     uint32_t bid = blockIdx.x;
     const uint32_t tx = bid % tiles_x; bid /= tiles_x;
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
     const uint32_t jidx = bid / tiles_y;
     const Job job = jobs[jidx];
     if (tx * 16u >= job.w || ty * 16u >= job.h) return;
-    const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
+    // each wave takes an 8x8 quarter of the tile (not a 16x4 strip): the per-pixel cull below only saves
+    // work when all 64 lanes agree, and a compact square agrees more often
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    const uint32_t x = tx * 16u + (wv & 1u) * 8u + (ln & 7u), y = ty * 16u + (wv >> 1) * 8u + (ln >> 3);
     const bool valid = x < job.w && y < job.h;
     const float off = phase_center ? 0.5f : 0.0f;
     const float qx = ((float)(job.min_x + (int32_t)x) + off) / job.scale;       // render_glyph.zig:26
@@ -103,12 +106,19 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
                 const uint32_t slot = atomicAdd(&s_n, 1u);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) s_seg[slot][k] = c[k];
+                s_seg[slot][6] = hx0; s_seg[slot][7] = hx1; s_seg[slot][8] = hy0; s_seg[slot][9] = hy1;
             }
         }
         __syncthreads();
         const uint32_t n = s_n;
         if (valid)
             for (uint32_t k = 0; k < n; ++k) {
+                // per pixel the same argument: the computed distance is >= the distance to the segment's box,
+                // so a box no nearer than the best so far (or than the saturation reach) changes nothing
+                const float gx = fmaxf(fmaxf(s_seg[k][6] - qx, qx - s_seg[k][7]), 0.0f);
+                const float gy = fmaxf(fmaxf(s_seg[k][8] - qy, qy - s_seg[k][9]), 0.0f);
+                const float g2 = gx * gx + gy * gy;
+                if (g2 >= best || g2 > reach * reach) continue;
                 const float d2 = seg_dist2(s_seg[k][0], s_seg[k][1], s_seg[k][2], s_seg[k][3], s_seg[k][4], s_seg[k][5], qx, qy);
                 if (d2 < best) best = d2;
             }
