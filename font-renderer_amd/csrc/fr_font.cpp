@@ -45,6 +45,7 @@ struct fr_font {
     size_t pos_loca = 0, pos_glyf = 0, pos_cmap_sub = 0;
     int cmap_format = 0;
     std::vector<GlyphData> glyphs;
+    size_t composite_depth = 0;     // load_composite frames currently on the stack
 
     bool has(size_t off, size_t n) const { return off <= d.size() && n <= d.size() - off; }
     uint16_t u16(size_t o) const { return (uint16_t)((d[o] << 8) | d[o + 1]); }
@@ -88,7 +89,7 @@ int32_t transform1(int16_t x, int16_t y, int16_t a_or_b, int16_t c_or_d, int16_t
     const int32_t tmp = aa > cc ? aa : cc;                                         // :179
     const int16_t diff = (int16_t)(uint16_t)((uint16_t)aa - (uint16_t)cc);
     const int32_t dabs = diff < 0 ? -(int32_t)diff : diff;
-    const int16_t shift = (int16_t)((int32_t)e_or_f << (dabs <= 8 ? 1 : 0));        // :180
+    const int16_t shift = (int16_t)((int32_t)e_or_f * (dabs <= 8 ? 2 : 1));         // :180 (a shift of a negative offset, written as a product)
     return (int32_t)a_or_b * x + (int32_t)c_or_d * y + tmp * (int32_t)shift;       // :181
 }
 int32_t round14(int32_t d)          // helpers.zig:112-123, bias_bits = 14
@@ -102,6 +103,8 @@ int32_t round14(int32_t d)          // helpers.zig:112-123, bias_bits = 14
 }
 
 int load_glyph(fr_font &f, uint16_t gi, std::vector<uint16_t> &track);
+constexpr size_t kMaxCompositeDepth = 64;          // nesting of composite glyphs (the reference recurses unbounded: Font.zig:204-216)
+constexpr size_t kMaxGlyphPoints = 1u << 20;       // expanded points of one glyph
 
 int load_simple(fr_font &f, GlyphData &g, size_t pos, uint16_t n_contours)
 {
@@ -238,6 +241,11 @@ int load_composite(fr_font &f, GlyphData &g, size_t pos, uint16_t self_index, st
     for (const Part &p : parts)
         if (p.flag & 0x0200) return set_error(FR_E_UNSUPPORTED, "use_my_metrics component (the reference panics: Glyph.zig:110)");
     // Font.zig:204-216: dependency-loop check (the stack is never popped in the reference), load parts
+    // (bounds the reference lacks: nesting depth and expanded size — a crafted chain of distinct
+    // composites would otherwise recurse ~65k deep or grow exponentially)
+    struct Depth { size_t &d; explicit Depth(size_t &x) : d(x) { ++d; } ~Depth() { --d; } } depth(f.composite_depth);
+    if (f.composite_depth > kMaxCompositeDepth)
+        return set_error(FR_E_UNSUPPORTED, "composite glyphs nested deeper than %u", (unsigned)kMaxCompositeDepth);
     track.push_back(self_index);
     for (const Part &p : parts) {
         for (uint16_t seen : track)
@@ -262,12 +270,14 @@ int load_composite(fr_font &f, GlyphData &g, size_t pos, uint16_t self_index, st
                     ox = round14(fx); oy = round14(fy);
                 } else {
                     ox = fx >> 14; oy = fy >> 14;                                    // :144-145
-                    if ((ox << 14) != fx || (oy << 14) != fy)
+                    if (ox * 16384 != fx || oy * 16384 != fy)
                         return set_error(FR_E_UNSUPPORTED, "fractional component offset without round_xy_to_grid (the reference panics: Glyph.zig:146)");
                 }
                 g.pts.push_back((int16_t)ox);
                 g.pts.push_back((int16_t)oy);
             }
+            if (g.pts.size() / 2 > kMaxGlyphPoints)
+                return set_error(FR_E_UNSUPPORTED, "composite glyph expands to more than %u points", (unsigned)kMaxGlyphPoints);
             g.cstart.push_back((uint32_t)(g.pts.size() / 2));
         }
     }

@@ -26,7 +26,7 @@ def compute(oracle, ascii_set):
         out[f"gray/{font}/{ch}/{size}"] = _h(oracle.render_glyph(g, upm, size))
         mn, mx, w, h, s = oracle.render_glyph_dims(g.box.as_array(), upm, size)
         out[f"cov4c/{font}/{ch}/{size}"] = _h(oracle.render_cell(g, mn[0], mx[1], w, h, s, O.COVERAGE_U8, 4, True))
-        out[f"lattice/{font}/{ch}"] = _h(oracle.winding_lattice(g).astype("<i2")) if ch == "A" else ""
+        out[f"lattice/{font}/{ch}"] = _h(oracle.winding_lattice(g).astype("<i2"))
     # a small atlas: 16 STIX glyphs, 32x32 cells, 2x2 centre samples
     jobs = cell_jobs(ascii_set.gs, 32, 30, ascii_set.g_upm, 4, first_glyph=33, n_glyphs=16)
     atlas = np.zeros((128, 128), np.uint8)
