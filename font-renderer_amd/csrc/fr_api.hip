@@ -12,11 +12,12 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 namespace fr {
-void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *, uint32_t *,
-                    hipStream_t);
+void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *,
+                    uint32_t *, hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 uint32_t render_wg_waves();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
@@ -86,6 +87,8 @@ struct fr_plan {
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
     uint32_t *d_job_seg = nullptr;     // [n_jobs][2]: first segment and segment count of the job's glyph
+    uint32_t *d_large = nullptr;       // distinct glyphs of more than 128 segments among the jobs: their records are
+    uint32_t n_large = 0;              // rebuilt by prepare_kernel before every render (the others: inside the render kernel)
     uint32_t n_jobs = 0;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
@@ -207,7 +210,7 @@ int fr_glyphset_prepare(fr_glyphset *gs)
 {
     if (!gs) return fail(FR_E_INVALID, "fr_glyphset_prepare: NULL");
     HIP_TRY(hipSetDevice(gs->ctx->device));
-    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, gs->n_glyphs, gs->d_recs,
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, nullptr, gs->n_glyphs, gs->d_recs,
                        gs->d_rec_count, gs->ctx->stream);
     HIP_TRY(hipGetLastError());
     return FR_OK;
@@ -266,7 +269,7 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
     gs->h_glyph_seg_start = gseg;
     GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
-    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, n_glyphs, gs->d_recs,
+    fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, nullptr, n_glyphs, gs->d_recs,
                        gs->d_rec_count, st);
     GS_TRY(hipGetLastError());
     GS_TRY(hipStreamSynchronize(st));   // host vectors above die with this frame
@@ -312,7 +315,7 @@ void fr_plan_destroy(fr_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    dfree(plan->d_jobs); dfree(plan->d_job_seg);
+    dfree(plan->d_jobs); dfree(plan->d_job_seg); dfree(plan->d_large);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
     delete plan;
@@ -382,6 +385,16 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         jseg[2 * (size_t)j] = gs->h_glyph_seg_start[jobs[j].glyph];
         jseg[2 * (size_t)j + 1] = gs->h_glyph_seg_start[jobs[j].glyph + 1] - gs->h_glyph_seg_start[jobs[j].glyph];
     }
+    // glyphs too large for the in-kernel record build (> 128 segments), each once
+    std::vector<uint32_t> large;
+    for (uint32_t j = 0; j < n_jobs; ++j)
+        if (jseg[2 * (size_t)j + 1] > 128u) large.push_back(jobs[j].glyph);
+    std::sort(large.begin(), large.end());
+    large.erase(std::unique(large.begin(), large.end()), large.end());
+    p->n_large = (uint32_t)large.size();
+    if (e == hipSuccess && p->n_large) e = hipMalloc(&p->d_large, large.size() * 4);
+    if (e == hipSuccess && p->n_large)
+        e = hipMemcpyAsync(p->d_large, large.data(), large.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_job_seg, (size_t)n_jobs * 8);
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_job_seg, jseg.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -414,8 +427,9 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.recs = plan->gs->d_recs;
     a.pts = plan->gs->d_pts;
     a.seg_p0 = plan->gs->d_seg_p0;
-    // fused: the render kernel builds each glyph's records in LDS itself (<= 256 candidate roots)
-    a.fused = (plan->ctx->fuse_prepare && plan->gs->max_seg_per_glyph <= 128u) ? 1u : 0u;
+    // fused: the render kernel builds the records of every glyph of <= 128 segments (<= 256 candidate roots)
+    // in LDS itself — decided per job inside the kernel; larger glyphs are staged from HBM
+    a.fused = plan->ctx->fuse_prepare ? 1u : 0u;
     a.uniform = plan->uniform ? 1u : 0u;
     a.out = out_dev;
     a.out_stride = out_stride;
@@ -436,7 +450,10 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     // a render always starts from the glyph POINTS: either inside the render kernel (fused) or by
     // re-running the stand-alone precompute first
     if (!a.fused)
-        fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->gs->n_glyphs,
+        fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, nullptr, plan->gs->n_glyphs,
+                           plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
+    else if (plan->n_large)
+        fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->d_large, plan->n_large,
                            plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
     if (plan->params.mode == FR_SDF_U8) {
         // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,

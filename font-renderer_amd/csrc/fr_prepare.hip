@@ -12,12 +12,14 @@ namespace fr {
 __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__ pts,
                                                      const uint32_t *__restrict__ seg_p0,
                                                      const uint32_t *__restrict__ glyph_seg_start,
+                                                     const uint32_t *__restrict__ glyph_list,
                                                      uint32_t n_glyphs,
                                                      Rec *__restrict__ out_recs,
                                                      uint32_t *__restrict__ glyph_rec_count)
 {
-    const uint32_t g = blockIdx.x;
-    if (g >= n_glyphs) return;
+    if (blockIdx.x >= n_glyphs) return;
+    // the whole set (list == nullptr), or only the listed glyphs (a plan's glyphs of more than 128 segments)
+    const uint32_t g = glyph_list ? glyph_list[blockIdx.x] : blockIdx.x;
     const uint32_t s0 = glyph_seg_start[g], s1 = glyph_seg_start[g + 1];
     const uint32_t n_cand = 2u * (s1 - s0);
     const uint32_t lane = threadIdx.x;
@@ -39,11 +41,12 @@ __global__ __launch_bounds__(64) void prepare_kernel(const int16_t *__restrict__
 }
 
 void launch_prepare(const int16_t *pts, const uint32_t *seg_p0, const uint32_t *glyph_seg_start,
-                    uint32_t n_glyphs, Rec *out_recs, uint32_t *glyph_rec_count, hipStream_t stream)
+                    const uint32_t *glyph_list, uint32_t n_glyphs, Rec *out_recs, uint32_t *glyph_rec_count,
+                    hipStream_t stream)
 {
     if (n_glyphs == 0) return;
     hipLaunchKernelGGL(prepare_kernel, dim3(n_glyphs), dim3(64), 0, stream, pts, seg_p0,
-                       glyph_seg_start, n_glyphs, out_recs, glyph_rec_count);
+                       glyph_seg_start, glyph_list, n_glyphs, out_recs, glyph_rec_count);
 }
 
 }  // namespace fr

@@ -242,7 +242,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];   // (loaded with the job)
     const Rec *grec = A.recs + 2u * (size_t)seg0;
     // fused: one slot per candidate root (2 per segment); else the compacted count of prepare_kernel
-    const uint32_t rec_cnt = A.fused ? 2u * nseg : A.glyph_rec_count[g];
+    // per JOB: a glyph of <= 128 segments has its records built here, in LDS; a larger one is staged from
+    // the stand-alone records prepare_kernel rebuilt for it just before this launch (workgroup-uniform)
+    const bool fused = A.fused && nseg <= 128u;
+    const uint32_t rec_cnt = fused ? 2u * nseg : A.glyph_rec_count[g];
 
     // LDS: padded cx table | staged records (<= 256, read-only while waves walk them) |
     //      per-wave half-band region (window masks or breakpoint rows) | per-wave fill[32]
@@ -283,9 +286,9 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
         r.hi = __builtin_bit_cast(float, re);
         return r;
     };
-    if (A.fused) {
+    if (fused) {
         // build my glyph's root records straight into LDS (candidate tid = root tid&1 of segment
-        // tid>>1; plans are fused only when every glyph has <= 128 segments): no separate
+        // tid>>1; only glyphs of <= 128 segments come here): no separate
         // prepare pass, no record traffic through HBM.  Slots of non-existent / provably empty
         // roots hold an empty interval and never pass a cull.
         const uint32_t s0g = seg0;

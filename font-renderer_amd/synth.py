@@ -80,10 +80,14 @@ def synth_glyph(index: int, n_segments: int):
 
 
 def synth_glyphset(n_glyphs: int, n_segments: int, first_index: int = 0) -> GlyphSet:
+    return _glyphset(synth_glyph, n_glyphs, n_segments, first_index)
+
+
+def _glyphset(make, n_glyphs: int, n_segments: int, first_index: int = 0) -> GlyphSet:
     pts, cstart, gstart, boxes = [], [0], [0], []
     n = 0
     for g in range(first_index, first_index + n_glyphs):
-        cs, box = synth_glyph(g, n_segments)
+        cs, box = make(g, n_segments)
         for c in cs:
             pts.append(c)
             n += len(c)
@@ -92,6 +96,70 @@ def synth_glyphset(n_glyphs: int, n_segments: int, first_index: int = 0) -> Glyp
         boxes.append(box)
     return GlyphSet.from_arrays(np.concatenate(pts), np.array(cstart, np.uint32), np.array(gstart, np.uint32),
                                 np.array(boxes, np.int16))
+
+
+def stroke_glyph(index: int, n_segments: int):
+    """Stroke-dense outline (a CJK-like crossing count, not just a CJK-like segment count): 8-16 thin
+    elongated closed splines ("strokes": 70 % vertical, 18 % horizontal, 12 % diagonal) scattered over the em,
+    all clockwise, so a horizontal ray meets 10-30 edges and strokes that overlap give winding 2 (non-zero fill
+    differs from even-odd there).  Same PRNG, contour layout and truncated-midpoint rule as synth_glyph.
+    -> (list of (len,2) int16 contour arrays, box[4])"""
+    S = int(n_segments)
+    assert S >= 32
+    rnd = splitmix64(0x57120CE5 ^ index, 8 + 16 * 8 + 4 * S + 64)
+    u = _uniform(rnd)
+    K = 8 + int(rnd[0] % np.uint64(9))
+    while S // K < 4:
+        K -= 1
+    counts = [S // K] * K
+    counts[0] += S - sum(counts)
+    contours, o = [], 8
+    for k, Sk in enumerate(counts):
+        pu = u[o:o + 8]; o += 8
+        uu = u[o:o + 4 * Sk]; o += 4 * Sk
+        kind = pu[0]
+        length = 1000.0 + 800.0 * pu[1]
+        thick = 40.0 + 70.0 * pu[2]
+        if kind < 0.70:
+            theta = np.pi / 2 + (pu[3] * 2 - 1) * 0.06            # vertical stroke
+        elif kind < 0.88:
+            theta = (pu[3] * 2 - 1) * 0.06                        # horizontal stroke
+        else:
+            theta = (np.pi / 4 if pu[3] < 0.5 else 3 * np.pi / 4) + (pu[4] * 2 - 1) * 0.2
+            length *= 0.8
+        cx0 = 250.0 + 1550.0 * pu[5]
+        cy0 = 250.0 + 1550.0 * pu[6]
+        i = np.arange(Sk)
+        ang = -2 * np.pi * (i + uu[0:Sk] * 0.5) / Sk             # clockwise in y-up font units
+        ra = 0.5 * length * (1 + 0.06 * (uu[Sk:2 * Sk] * 2 - 1))
+        rb = 0.5 * thick * (1 + 0.25 * (uu[Sk:2 * Sk] * 2 - 1))
+        ct, st = np.cos(theta), np.sin(theta)
+
+        def place(a, ra_, rb_):
+            ex, ey = ra_ * np.cos(a), rb_ * np.sin(a)
+            return np.stack([cx0 + ex * ct - ey * st, cy0 + ex * st + ey * ct], 1)
+        on = np.clip(np.rint(place(ang, ra, rb)), LO, HI).astype(np.int64)
+        nxt = np.roll(on, -1, 0)
+        ang_n = np.roll(ang, -1)
+        ang_n[-1] -= 2 * np.pi
+        mid = 0.5 * (ang + ang_n)
+        half = 0.5 * np.abs(ang_n - ang)
+        grow = 1.0 / np.maximum(np.cos(half), 0.3) * (1 + 0.1 * (uu[2 * Sk:3 * Sk] * 2 - 1))
+        ctrl = np.clip(np.rint(place(mid, 0.5 * (ra + np.roll(ra, -1)) * grow, 0.5 * (rb + np.roll(rb, -1)) * grow)), LO, HI).astype(np.int64)
+        straight = uu[3 * Sk:4 * Sk] < 0.2
+        ctrl[straight] = _div_trunc2(on[straight] + nxt[straight])        # Point.initMiddle
+        pts = np.empty((2 * Sk + 1, 2), np.int64)
+        pts[0:2 * Sk:2] = on
+        pts[1:2 * Sk:2] = ctrl
+        pts[2 * Sk] = on[0]
+        contours.append(pts.astype(np.int16))
+    allp = np.concatenate(contours)
+    box = np.array([allp[:, 0].min(), allp[:, 1].min(), allp[:, 0].max(), allp[:, 1].max()], np.int16)
+    return contours, box
+
+
+def stroke_glyphset(n_glyphs: int, n_segments: int, first_index: int = 0) -> GlyphSet:
+    return _glyphset(stroke_glyph, n_glyphs, n_segments, first_index)
 
 
 def comb_glyph(teeth: int, width: int = 1800, height: int = 1500):

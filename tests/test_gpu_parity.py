@@ -10,7 +10,7 @@ import oracle_lib as O
 from font_renderer_amd import render_glyph as rg
 from font_renderer_amd.atlas import atlas_shape, cell_jobs
 from font_renderer_amd.glyph import Box, Contour, Glyph, GlyphSet
-from font_renderer_amd.synth import comb_glyph, synth_glyphset
+from font_renderer_amd.synth import comb_glyph, stroke_glyphset, synth_glyphset
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +82,38 @@ def test_coverage_synthetic(ctx, oracle, segs, cell):
     got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(n_g, cell, 4), 4, True)
     assert np.array_equal(got, ref)
     assert 0.05 < (ref > 0).mean() < 0.95
+
+
+def test_mixed_glyph_sizes_in_one_plan(ctx, oracle):
+    """The fused / staged decision is per JOB: one plan holding glyphs of 24, 128, 129, 200 and 520
+    segments (the last one needs three 256-record chunks) renders every cell like the oracle; the small
+    glyphs keep taking the in-kernel record build whatever else is in the set."""
+    parts = [synth_glyphset(2, 24, first_index=11), synth_glyphset(2, 128, first_index=12),
+             synth_glyphset(1, 129, first_index=13), synth_glyphset(2, 200, first_index=14),
+             synth_glyphset(1, 520, first_index=15), synth_glyphset(2, 64, first_index=16)]
+    gl = [p.glyph(i) for p in parts for i in range(len(p))]
+    gs = GlyphSet(gl)
+    for cell, n in ((128, 4), (256, 4), (96, 2), (80, 1)):
+        jobs = cell_jobs(gs, cell, cell, 2048, 5)
+        got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(len(gs), cell, 5), n, True, threads=16)
+        assert np.array_equal(got, ref), (cell, n)
+    jobs = cell_jobs(gs, 64, 64, 2048, 5)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_WINDING_I16, atlas_shape(len(gs), 64, 5), 1, False, threads=16)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("segs,cell", [(64, 128), (128, 256), (200, 256)])
+def test_coverage_stroke_dense(ctx, oracle, segs, cell):
+    """stroke-dense outlines (8-16 thin strokes per glyph: 10-30 crossings per ray, overlapping strokes
+    give winding 2), 16 samples per pixel: every sort tier and over-full rows at the default kmax"""
+    n_g = 6
+    gs = stroke_glyphset(n_g, segs, first_index=300 + segs)
+    jobs = cell_jobs(gs, cell, cell, 2048, 3)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(n_g, cell, 3), 4, True, threads=16)
+    assert np.array_equal(got, ref)
+    w, wref = _batch_both(ctx, oracle, gs, jobs, fr.FR_WINDING_I16, atlas_shape(n_g, cell, 3), 1, False, threads=16)
+    assert np.array_equal(w, wref)
+    assert wref.max() >= 2          # overlapping strokes: non-zero fill is not even-odd here
 
 
 def test_ragged_cells_unaligned_output(ctx, oracle, ascii_set):
