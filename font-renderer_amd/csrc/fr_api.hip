@@ -20,6 +20,9 @@ void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const u
                     uint32_t *, hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 uint32_t render_wg_waves();
+hipError_t launch_cov4(const RenderArgs &, hipStream_t);
+uint32_t cov4_wg_waves();
+uint32_t cov4_max_segments();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, int, uint8_t *,
                        uint8_t *, hipStream_t);
@@ -70,16 +73,18 @@ struct fr_ctx {
     uint32_t fuse_prepare = 1;   // build root records inside the render kernel when every glyph has <= 128 segments
     uint32_t lds_pad = 0;        // experiment knob: extra dynamic LDS bytes per workgroup (occupancy studies)
     uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
+    uint32_t cov4 = 1;           // 16-sample coverage of uniform cells takes cov4_kernel (fr_cov4.hip) where it fits
 };
 
 struct fr_glyphset {
     fr_ctx *ctx = nullptr;
     uint32_t n_glyphs = 0, n_contours = 0, n_seg = 0, max_seg_per_glyph = 0;
     uint64_t n_points = 0;
-    int16_t *d_pts = nullptr;
+    int16_t *d_pts = nullptr, *d_seg_pts = nullptr;
     uint32_t *d_seg_p0 = nullptr, *d_seg_prev = nullptr, *d_glyph_seg_start = nullptr, *d_rec_count = nullptr;
     fr::Rec *d_recs = nullptr;
     std::vector<uint32_t> h_glyph_seg_start;    // host copy: plans attach each job's segment range to it
+    std::vector<uint32_t> h_root_bound;         // per glyph: candidate roots the vertex rule cannot discard (>= live records)
 };
 
 struct fr_plan {
@@ -90,6 +95,11 @@ struct fr_plan {
     uint32_t *d_large = nullptr;       // distinct glyphs of more than 128 segments among the jobs: their records are
     uint32_t n_large = 0;              // rebuilt by prepare_kernel before every render (the others: inside the render kernel)
     uint32_t n_jobs = 0;
+    // jobs cov4_kernel takes (fr_cov4.hip: 16-sample coverage, uniform cells, <= 256 root records): the first n_fast
+    // entries of d_jobs / d_job_seg; the general kernel renders the other n_jobs - n_fast
+    uint32_t n_fast = 0;
+    uint32_t fast_bands = 0, fast_strips = 0, gen_bands = 0, gen_strips = 0;
+    bool gen_uniform = false;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
     bool uniform = false;        // see fr_plan_create
@@ -160,6 +170,7 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
     }
     if (!strcmp(key, "fuse_prepare")) { ctx->fuse_prepare = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
+    if (!strcmp(key, "cov4")) { ctx->cov4 = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "min_wgs")) {
         if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
         ctx->min_wgs = (uint32_t)value;
@@ -201,7 +212,7 @@ void fr_glyphset_destroy(fr_glyphset *gs)
     if (!gs) return;
     (void)hipSetDevice(gs->ctx->device);
     (void)hipStreamSynchronize(gs->ctx->stream);
-    dfree(gs->d_pts); dfree(gs->d_seg_p0); dfree(gs->d_seg_prev); dfree(gs->d_glyph_seg_start);
+    dfree(gs->d_pts); dfree(gs->d_seg_pts); dfree(gs->d_seg_p0); dfree(gs->d_seg_prev); dfree(gs->d_glyph_seg_start);
     dfree(gs->d_rec_count); dfree(gs->d_recs);
     delete gs;
 }
@@ -239,6 +250,23 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     }
     uint32_t max_seg = 0;
     for (uint32_t g = 0; g < n_glyphs; ++g) max_seg = std::max(max_seg, gseg[g + 1] - gseg[g]);
+    // Upper bound of the root records a render can keep per glyph: the two candidates of a segment minus those
+    // build_record_rows (fr_records.hpp) discards without looking at a cell — a == 0: one root, none if p2y == p0y
+    // (render_glyph.zig:49-50); else the far-side root when t_v = B/a >= 1 and the near-side root when t_v < 0.
+    std::vector<uint32_t> root_bound(n_glyphs, 0u);
+    for (uint32_t g = 0; g < n_glyphs; ++g) {
+        uint32_t nb = 0;
+        for (uint32_t sgi = gseg[g]; sgi < gseg[g + 1]; ++sgi) {
+            const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
+            const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
+            const int32_t a = p0y - 2 * p1y + p2y, b = p0y - p1y;
+            if (a == 0) { nb += (p2y != p0y) ? 1u : 0u; continue; }
+            const int64_t ba = (int64_t)b * a;
+            const bool tv_lt0 = ba < 0, tv_ge1 = a > 0 ? b >= a : b <= a;
+            nb += (tv_ge1 ? 0u : 1u) + (tv_lt0 ? 0u : 1u);
+        }
+        root_bound[g] = nb;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     fr_glyphset *gs = new (std::nothrow) fr_glyphset;
     if (!gs) return fail(FR_E_NOMEM, "fr_glyphset_create: host allocation");
@@ -255,6 +283,7 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
         }                                                                                     \
     } while (0)
     GS_TRY(hipMalloc(&gs->d_pts, np1 * 2 * sizeof(int16_t) + 16));
+    GS_TRY(hipMalloc(&gs->d_seg_pts, nseg1 * 12 + 16));
     GS_TRY(hipMalloc(&gs->d_seg_p0, nseg1 * 4));
     GS_TRY(hipMalloc(&gs->d_seg_prev, nseg1 * 4));
     GS_TRY(hipMalloc(&gs->d_glyph_seg_start, ((size_t)n_glyphs + 1) * 4));
@@ -262,12 +291,16 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     GS_TRY(hipMalloc(&gs->d_recs, 2 * nseg1 * sizeof(fr::Rec)));
     hipStream_t st = ctx->stream;
     if (np) GS_TRY(hipMemcpyAsync(gs->d_pts, points_xy, np * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    std::vector<int16_t> seg_pts((size_t)gs->n_seg * 6);
+    for (size_t sgi = 0; sgi < gs->n_seg; ++sgi) memcpy(&seg_pts[6 * sgi], points_xy + 2u * (size_t)seg_p0[sgi], 12);
     if (gs->n_seg) {
+        GS_TRY(hipMemcpyAsync(gs->d_seg_pts, seg_pts.data(), (size_t)gs->n_seg * 12, hipMemcpyHostToDevice, st));
         GS_TRY(hipMemcpyAsync(gs->d_seg_p0, seg_p0.data(), (size_t)gs->n_seg * 4, hipMemcpyHostToDevice, st));
         GS_TRY(hipMemcpyAsync(gs->d_seg_prev, seg_prev.data(), (size_t)gs->n_seg * 4, hipMemcpyHostToDevice, st));
     }
     GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
     gs->h_glyph_seg_start = gseg;
+    gs->h_root_bound = root_bound;
     GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
     fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, nullptr, n_glyphs, gs->d_recs,
                        gs->d_rec_count, st);
@@ -365,30 +398,60 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     p->strip_w = sw;
     p->bands = max_h ? (max_h + band - 1) / band : 1;
     p->strips = max_w ? (max_w + sw - 1) / sw : 1;
-    // uniform: every strip of every job is full (w a multiple of the strip width) and every wave band is
-    // full (h a multiple of 64 / n pixel rows) — atlas cells; the render kernel has instances for it
-    p->uniform = n_jobs > 0;
-    for (uint32_t j = 0; j < n_jobs; ++j)
-        if (jobs[j].w == 0 || jobs[j].h == 0 || jobs[j].w % sw || jobs[j].h % band) { p->uniform = false; break; }
+    // Per JOB: cov4_kernel (fr_cov4.hip) takes 16-sample coverage of cells that are whole 128- / 256-pixel strips
+    // wide, whole wave bands (16 pixel rows) and at most 256 pixels tall, of glyphs with at most 256 segments and
+    // 256 possible root records; the general kernel takes the rest.  The job table is stored fast jobs first.
+    std::vector<uint32_t> order(n_jobs);
+    uint32_t n_fast = 0;
+    {
+        const bool mode_ok = ctx->cov4 && params->mode == FR_COVERAGE_U8 && n == 4u && (sw == 128u || sw == 256u);
+        std::vector<uint32_t> slow;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            const fr_job &jb = jobs[j];
+            const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
+            const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= 256u &&
+                              nsg <= fr::cov4_max_segments() && gs->h_root_bound[jb.glyph] <= 256u;
+            if (fast) order[n_fast++] = j; else slow.push_back(j);
+        }
+        std::copy(slow.begin(), slow.end(), order.begin() + n_fast);
+    }
+    p->n_fast = n_fast;
+    // the general list: uniform = every strip of every job is full (w a multiple of the strip width) and every wave
+    // band is full (h a multiple of 64 / n pixel rows) — atlas cells; the render kernel has instances for it
+    p->uniform = n_jobs > n_fast;
+    uint32_t gmax_w = 0, gmax_h = 0, fmax_w = 0, fmax_h = 0;
+    for (uint32_t q = 0; q < n_jobs; ++q) {
+        const fr_job &jb = jobs[order[q]];
+        if (q < n_fast) { fmax_w = std::max(fmax_w, jb.w); fmax_h = std::max(fmax_h, jb.h); continue; }
+        gmax_w = std::max(gmax_w, jb.w); gmax_h = std::max(gmax_h, jb.h);
+        if (jb.w == 0 || jb.h == 0 || jb.w % sw || jb.h % band) p->uniform = false;
+    }
+    p->gen_bands = gmax_h ? (gmax_h + band - 1) / band : 1;
+    p->gen_strips = gmax_w ? (gmax_w + sw - 1) / sw : 1;
+    p->fast_bands = fmax_h / 16u;
+    p->fast_strips = fmax_w ? fmax_w / sw : 1;
     if ((uint64_t)n_jobs * p->bands * p->strips > 0x7fffffffull) {
         delete p;
         return fail(FR_E_UNSUPPORTED, "batch needs more than 2^31 workgroups; split it");
     }
+    std::vector<fr_job> sorted_jobs(n_jobs);
+    for (uint32_t q = 0; q < n_jobs; ++q) sorted_jobs[q] = jobs[order[q]];
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
     if (e == hipSuccess && n_jobs)
-        e = hipMemcpyAsync(p->d_jobs, jobs, (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(p->d_jobs, sorted_jobs.data(), (size_t)n_jobs * sizeof(fr::Job), hipMemcpyHostToDevice, ctx->stream);
     // each job's segment range, next to the job: the render kernel starts on the glyph's points without a
     // dependent look-up through the glyph table
     std::vector<uint32_t> jseg((size_t)n_jobs * 2);
-    for (uint32_t j = 0; j < n_jobs; ++j) {
-        jseg[2 * (size_t)j] = gs->h_glyph_seg_start[jobs[j].glyph];
-        jseg[2 * (size_t)j + 1] = gs->h_glyph_seg_start[jobs[j].glyph + 1] - gs->h_glyph_seg_start[jobs[j].glyph];
+    for (uint32_t q = 0; q < n_jobs; ++q) {
+        const uint32_t gl = sorted_jobs[q].glyph;
+        jseg[2 * (size_t)q] = gs->h_glyph_seg_start[gl];
+        jseg[2 * (size_t)q + 1] = gs->h_glyph_seg_start[gl + 1] - gs->h_glyph_seg_start[gl];
     }
-    // glyphs too large for the in-kernel record build (> 128 segments), each once
+    // glyphs too large for the in-kernel record build (> 128 segments) among the general kernel's jobs, each once
     std::vector<uint32_t> large;
-    for (uint32_t j = 0; j < n_jobs; ++j)
-        if (jseg[2 * (size_t)j + 1] > 128u) large.push_back(jobs[j].glyph);
+    for (uint32_t q = n_fast; q < n_jobs; ++q)
+        if (jseg[2 * (size_t)q + 1] > 128u) large.push_back(sorted_jobs[q].glyph);
     std::sort(large.begin(), large.end());
     large.erase(std::unique(large.begin(), large.end()), large.end());
     p->n_large = (uint32_t)large.size();
@@ -419,50 +482,64 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     if (plan->need_cols > out_stride || plan->need_rows > out_rows)
         return fail(FR_E_INVALID, "jobs need %llu x %llu elements, output is %zu x %zu",
                     (unsigned long long)plan->need_cols, (unsigned long long)plan->need_rows, out_stride, out_rows);
+    HIP_TRY(hipSetDevice(plan->ctx->device));
+    const uint32_t n_fast = plan->n_fast, n_gen = plan->n_jobs - plan->n_fast;
+    const bool sdf = plan->params.mode == FR_SDF_U8;
     fr::RenderArgs a;
-    a.jobs = plan->d_jobs;
     a.glyph_seg_start = plan->gs->d_glyph_seg_start;
-    a.job_seg = plan->d_job_seg;
     a.glyph_rec_count = plan->gs->d_rec_count;
     a.recs = plan->gs->d_recs;
     a.pts = plan->gs->d_pts;
     a.seg_p0 = plan->gs->d_seg_p0;
+    a.seg_pts = plan->gs->d_seg_pts;
     // fused: the render kernel builds the records of every glyph of <= 128 segments (<= 256 candidate roots)
     // in LDS itself — decided per job inside the kernel; larger glyphs are staged from HBM
     a.fused = plan->ctx->fuse_prepare ? 1u : 0u;
-    a.uniform = plan->uniform ? 1u : 0u;
     a.out = out_dev;
     a.out_stride = out_stride;
-    a.n_jobs = plan->n_jobs; a.bands = plan->bands; a.strips = plan->strips; a.strip_w = plan->strip_w;
+    a.strip_w = plan->strip_w;
     a.kmax = plan->ctx->kmax;
     a.phase_center = plan->params.sample_phase == FR_SAMPLE_CENTER ? 1 : 0;
     a.lds_pad = plan->ctx->lds_pad;
     a.nwin_log = 0; a.lds_region = 0; a.lds_rec_bytes = 0; a.lds_wave_bytes = 0; a.lds_tail = 0;
     // one workgroup walks all bands of its cell (cx table, job and records staged once)
     // unless the batch is too small to fill the chip: then split the bands over workgroups
-    // (bands are wave bands of 64/n pixel rows; a workgroup's 4 waves take them round-robin)
-    const uint32_t nw = fr::render_wg_waves();
-    uint32_t bpw = (plan->bands + nw - 1u) / nw * nw;
-    while (bpw > nw && (uint64_t)plan->n_jobs * plan->strips * ((plan->bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + nw - 1u) / nw * nw;
-    a.bands_per_wg = bpw;
-    a.band_groups = (plan->bands + bpw - 1) / bpw;
-    HIP_TRY(hipSetDevice(plan->ctx->device));
-    // a render always starts from the glyph POINTS: either inside the render kernel (fused) or by
-    // re-running the stand-alone precompute first
-    if (!a.fused)
+    // (bands are wave bands of 64/n pixel rows; a workgroup's waves take them round-robin)
+    auto split_bands = [&](uint32_t nw, uint32_t njobs, uint32_t bands, uint32_t strips) {
+        uint32_t bpw = (bands + nw - 1u) / nw * nw;
+        while (bpw > nw && (uint64_t)njobs * strips * ((bands + bpw - 1) / bpw) < plan->ctx->min_wgs) bpw = ((bpw / 2) + nw - 1u) / nw * nw;
+        a.bands_per_wg = bpw;
+        a.band_groups = (bands + bpw - 1) / bpw;
+    };
+    // a render always starts from the glyph POINTS: inside the kernels (fused) or by re-running the stand-alone
+    // precompute first, for the glyphs that need it
+    if (n_gen && !a.fused)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, nullptr, plan->gs->n_glyphs,
                            plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
-    else if (plan->n_large)
+    else if (n_gen && plan->n_large)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->d_large, plan->n_large,
                            plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
-    if (plan->params.mode == FR_SDF_U8) {
-        // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,
-        // same sample points) lands in the output; the distance kernel reads it and overwrites it
-        HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
-        HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
-        return FR_OK;
+    if (n_fast) {
+        a.jobs = plan->d_jobs;
+        a.job_seg = plan->d_job_seg;
+        a.n_jobs = n_fast; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
+        split_bands(fr::cov4_wg_waves(), n_fast, plan->fast_bands, plan->fast_strips);
+        HIP_TRY(fr::launch_cov4(a, plan->ctx->stream));
     }
-    HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
+    if (n_gen) {
+        a.jobs = plan->d_jobs + n_fast;
+        a.job_seg = plan->d_job_seg + 2u * (size_t)n_fast;
+        a.n_jobs = n_gen; a.bands = plan->gen_bands; a.strips = plan->gen_strips; a.uniform = plan->uniform ? 1u : 0u;
+        split_bands(fr::render_wg_waves(), n_gen, plan->gen_bands, plan->gen_strips);
+        if (sdf) {
+            // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,
+            // same sample points) lands in the output; the distance kernel reads it and overwrites it
+            HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
+            HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
+            return FR_OK;
+        }
+        HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
+    }
     return FR_OK;
 }
 

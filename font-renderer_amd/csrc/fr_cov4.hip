@@ -1,0 +1,635 @@
+// fr_cov4.hip — the headline instance of the hot path: 16-sample (4 x 4) anti-aliased coverage of atlas
+// cells, rebuilt around what bounds it on gfx950.  Same integers as render_kernel<COVERAGE_U8, 4> of
+// fr_render.hip (and therefore as the reference's glyphWindingAt per sample,
+// /root/reference/src/tools/render_glyph.zig:35-73, non-zero fill :29, box filter = the MSAA average
+// resolve of VulkanContext.zig:307-313); a plan takes this kernel for every job it fits (uniform cells,
+// <= 256 live root records) and the general kernel for the rest.
+//
+// What the round-2 measurements say (tools/ubench/issue_model*.hip, profiles/r02/issue_model*.txt):
+// the path is bound by VECTOR-ALU ISSUE TIME — scalar, LDS and branch instructions of one wave hide under
+// the vector instructions of the others.  A wave64 vector instruction holds its SIMD for ~4 cycles, except
+// a "fast class" (VOP2 add/sub/and/or/xor/lshrrev/mov on VGPRs or literals, v_add_f32 / v_sub_f32 /
+// v_mul_f32) that takes ~2 — but only with an EVEN number of waves per SIMD (at 3 waves/SIMD they cost
+// 1.8x); v_sqrt_f32 ~7; a VOP2 v_cndmask whose VCC was not written by the instruction right before it
+// ~10-19.  So this kernel (1) runs 8-wave workgroups, two per CU = 4 waves per SIMD; (2) turns the
+// inside masks + transpose + popcount of the general kernel into signed byte DIFFERENCES of coverage that
+// the window lanes integrate with a handful of fast adds (below); (3) keeps selects next to their compares
+// or on SGPR masks; (4) drops work whose result is already known (the acceptance tests inside an exact
+// row range).
+//
+// Coverage by integration.  For one sample row the inside set is a union of prefix intervals with signs:
+//   inside(j) = sum_k sigma_k [j < J_k],  sigma_k = [w_left != 0] - [w_right != 0]  (non-zero rule)
+// over the row's crossings sorted by J (w_right / w_left = winding right / left of crossing k).  The number
+// of inside samples of pixel p (4 sample columns) from prefix [0, J) is clamp(J - 4p, 0, 4), i.e.
+//   4 sigma + prefix-sum over q <= p of e[q],   e[P] = sigma (f - 4), e[P + 1] = -sigma f,  P = J >> 2, f = J & 3.
+// Every toggle therefore adds two small signed numbers to a byte array E[pixel row][pixel] (LDS, ds_add_u32
+// on the dword holding the bytes; bytes start at a bias of 16 so the final fields never borrow), the row's
+// constant 4 [w(0) != 0] goes to byte 0, and a window lane (16 pixels of one pixel row) integrates: a
+// multiply by 0x01010101 per dword, a 3-step chain across its 4 dwords, a 4-step DPP scan across the 16
+// windows of the row — then maps 16 counts to bytes at once.  Integer all the way: the result is the same
+// count k of inside samples per pixel, u8 = 16 k - [k > 8] = round_half_up(255 k / 16).
+#include "fr_records.hpp"
+
+namespace fr {
+
+#ifndef FR_C4_WAVES
+#define FR_C4_WAVES 4
+#endif
+#ifndef FR_C4_OCC
+#define FR_C4_OCC 4
+#endif
+#ifndef FR_C4_PCAP
+#define FR_C4_PCAP 384
+#endif
+#ifndef FR_C4_LSTRIDE
+#define FR_C4_LSTRIDE 36
+#endif
+// PCAP: (record, row) pairs laid out per round (a multiple of 64).  LSTRIDE: u16 slots per row list — 32 kept + the
+// dump slot + padding; a multiple of 4 (8-byte rows), 16-byte rows when a multiple of 8
+enum { C4_WAVES = FR_C4_WAVES, C4_PCAP = FR_C4_PCAP, C4_LSTRIDE = FR_C4_LSTRIDE };
+// 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
+__device__ __forceinline__ uint4 c4_ld16(const uint16_t *p)
+{
+    if ((C4_LSTRIDE * 2) % 16 == 0) return *reinterpret_cast<const uint4 *>(p);
+    const uint2 a = reinterpret_cast<const uint2 *>(p)[0], b = reinterpret_cast<const uint2 *>(p)[1];
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void c4_st16(uint16_t *p, uint4 v)
+{
+    if ((C4_LSTRIDE * 2) % 16 == 0) { *reinterpret_cast<uint4 *>(p) = v; return; }
+    reinterpret_cast<uint2 *>(p)[0] = make_uint2(v.x, v.y);
+    reinterpret_cast<uint2 *>(p)[1] = make_uint2(v.z, v.w);
+}
+
+// 40-byte root record of the cov4 kernel (LDS only)
+struct __attribute__((aligned(8))) Rec40 {
+    float a;        // quadratic: p0y - 2 p1y + p2y (:48); linear (a == 0 branch): the divisor p2y - p0y (:51)
+    float b;        // quadratic: p0y - p1y;               linear: p0y
+    float c1, c2;   // quadratic: p1y^2, p0y p2y (:58);    linear: 0
+    float ax, bx, p0x;   // (:53 / :65)
+    float rden;     // RN(1 / a)
+    float sgn;      // +1 for the t+ root, -1 for t-  (sqrt * +-1 is exact: B - sqrt == B + (-sqrt))
+    uint32_t fr;    // ra | re << 11 | cb << 22 | zb << 24 | linear << 31: sample rows [ra, re) accept the root;
+                    // the crossing's step code is (dy > 0) ? zb : cb   (2: +1, 0: -1; :55, :68)
+};
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t c4_dpp0(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t c4_dppm(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t c4_wave_incl_add(uint32_t x)
+{
+    x += c4_dppm<0x111, 0xf>(x);
+    x += c4_dppm<0x112, 0xf>(x);
+    x += c4_dppm<0x114, 0xf>(x);
+    x += c4_dppm<0x118, 0xf>(x);
+    x += c4_dppm<0x142, 0xa>(x);
+    x += c4_dppm<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t c4_wave_incl_max(uint32_t x)
+{
+    x = max(x, c4_dppm<0x111, 0xf>(x));
+    x = max(x, c4_dppm<0x112, 0xf>(x));
+    x = max(x, c4_dppm<0x114, 0xf>(x));
+    x = max(x, c4_dppm<0x118, 0xf>(x));
+    x = max(x, c4_dppm<0x142, 0xa>(x));
+    x = max(x, c4_dppm<0x143, 0xc>(x));
+    return x;
+}
+// select on a wave mask held in SGPRs — the VOP3 form, whose cost does not depend on what wrote the mask
+// (a VOP2 v_cndmask reading a VCC that is not fresh costs 3-5 vector instructions: profiles/r02/issue_model3.txt)
+__device__ __forceinline__ uint32_t c4_sel(unsigned long long m, uint32_t if_set, uint32_t if_clear)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float c4_self(unsigned long long m, float if_set, float if_clear)
+{
+    return __builtin_bit_cast(float, c4_sel(m, __builtin_bit_cast(uint32_t, if_set), __builtin_bit_cast(uint32_t, if_clear)));
+}
+__device__ __forceinline__ void c4_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+typedef unsigned short c4_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void c4_pce(uint32_t &a, uint32_t &b)
+{
+    const c4_u16x2 x = __builtin_bit_cast(c4_u16x2, a), y = __builtin_bit_cast(c4_u16x2, b);
+    a = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+    b = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, y));
+}
+// 2H crossings packed two per register, ascending: low halves = s[0..H), high halves = s[H..2H)
+// (the packed odd-even merge network of fr_render.hip)
+template <int H>
+__device__ __forceinline__ void c4_packed_sort(uint32_t (&d)[16])
+{
+#pragma unroll
+    for (int p = 1; p < H; p *= 2)
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (int j = k % p; j + k < H; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; ++i)
+                    if (i + j + k < H && (i + j) / (2 * p) == (i + j + k) / (2 * p)) c4_pce(d[i + j], d[i + j + k]);
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) {
+        const uint32_t x = d[j], y = d[H - 1 - j];
+        const uint32_t ys = __builtin_amdgcn_alignbit(y, y, 16);
+        const c4_u16x2 xv = __builtin_bit_cast(c4_u16x2, x), yv = __builtin_bit_cast(c4_u16x2, ys);
+        const uint32_t mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(xv, yv));
+        const uint32_t mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(xv, yv));
+        d[j] = __builtin_amdgcn_perm(mx, mn, 0x05040100u);
+        d[H - 1 - j] = __builtin_amdgcn_perm(mx, mn, 0x07060302u);
+    }
+#pragma unroll
+    for (int k = H / 2; k >= 1; k /= 2)
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            if (!(j & k)) c4_pce(d[j], d[j + k]);
+}
+
+// LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
+template <int WLOG>
+struct C4Lds {
+    static constexpr uint32_t NCOL = (16u << WLOG) * 4u;                    // sample columns of a strip
+    static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;         // padded cx table
+    static constexpr uint32_t REC = 256u * (uint32_t)sizeof(Rec40);
+    static constexpr uint32_t EROW = (16u << WLOG) + 16u;                   // bytes per pixel row of E (one 16-B pad)
+    static constexpr uint32_t E = 16u * EROW;
+    // walk buffers: lists [64][LSTRIDE] u16 | markers [PCAP] u16 | cy [64] f32 | cnt [64] u32 | roff [256] i16
+    static constexpr uint32_t LISTS = 64u * C4_LSTRIDE * 2u;
+    static constexpr uint32_t OFF_PAIRS = LISTS;
+    static constexpr uint32_t OFF_CY = OFF_PAIRS + C4_PCAP * 2u;
+    static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
+    static constexpr uint32_t OFF_ROFF = OFF_CNT + 256u;
+    static constexpr uint32_t WALK = OFF_ROFF + 512u;
+    static constexpr uint32_t WAVE = (WALK > E ? WALK : E);
+    static constexpr uint32_t OFF_WAVES = CX + REC;
+    static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
+    static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
+};
+
+// One workgroup (8 waves) = one cell (or one group of its wave bands, or one 256-px strip of it).
+// WLOG: strip width 16 << WLOG pixels (3: 128, 4: 256).  CAP: crossings a sample row keeps (8 / 16 / 32);
+// fuller rows take the direct sum over the glyph's stand-alone records, as in the general kernel.
+template <int WLOG, int CAP>
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
+void cov4_kernel(const RenderArgs A)
+{
+    using L = C4Lds<WLOG>;
+    constexpr uint32_t NW = C4_WAVES;
+    constexpr uint32_t SW = 16u << WLOG;            // strip width, pixels
+    constexpr uint32_t NCOL = SW * 4u;              // sample columns
+    constexpr uint32_t NWIN = 1u << WLOG;           // 16-pixel windows per pixel row
+    constexpr uint32_t EMPTY = 0xfffdu;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
+    if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
+    if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
+    const uint32_t jidx = bid;
+    const Job job = A.jobs[jidx];
+    const uint32_t x0s = strip * SW;
+    const uint32_t band_first = bgrp * A.bands_per_wg;
+    if (band_first * 16u >= job.h || x0s >= job.w) return;                  // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, job.h / 16u);
+    const int phase = A.phase_center;
+    const uint32_t g = job.glyph;
+    const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
+
+    float *s_cxp = reinterpret_cast<float *>(smem);
+    Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
+    unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
+    uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
+
+    // ---- set-up: candidate roots tid, tid + 256 (<= 256 segments), exact sample-row ranges, compaction
+    const uint32_t Hs = job.h * 4u;
+    constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
+    Rec40 mine[CPT];
+    unsigned long long lm[CPT];
+#pragma unroll
+    for (uint32_t it = 0; it < CPT; ++it) {
+        const uint32_t c = tid + it * 64u * NW;
+        bool live = false;
+        if (c < 2u * nseg) {                                                // (workgroup-uniform for it > 0: whole waves)
+            Rec r;
+            RowGeom geo;
+            geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = 4; geo.phase = phase;
+            build_record_rows(A.seg_pts + 6u * (size_t)(seg0 + (c >> 1)), c & 1u, geo, r);
+            const uint32_t ra = __builtin_bit_cast(uint32_t, r.lo), re = __builtin_bit_cast(uint32_t, r.hi);
+            live = ra < re;
+            const bool lin = (int32_t)r.flags < 0;
+            mine[it].a = lin ? r.c1 : r.a;
+            mine[it].b = r.b; mine[it].c1 = lin ? 0.0f : r.c1; mine[it].c2 = r.c2;
+            mine[it].ax = r.ax; mine[it].bx = r.bx; mine[it].p0x = r.p0x; mine[it].rden = r.rden;
+            mine[it].sgn = r.sqsign ? -1.0f : 1.0f;
+            const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
+            mine[it].fr = ra | (re << 11) | (cb << 22) | (zb << 24) | (lin ? 0x80000000u : 0u);
+        }
+        lm[it] = __ballot(live);
+        if (lane == 0) s_wcnt[it * NW + wave] = (uint32_t)__popcll(lm[it]);
+    }
+    // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
+    const int32_t min_xs = job.min_x + (int32_t)x0s;
+    for (uint32_t j = tid; j < NCOL; j += 64u * NW)
+        s_cxp[1u + j] = ((float)(min_xs + (int32_t)(j >> 2)) + sub_off((int)(j & 3u), 4, phase)) / job.scale;
+    if (tid == 2) s_cxp[0] = -__builtin_inff();
+    if (tid == 3) s_cxp[1u + NCOL] = __builtin_inff();
+    __syncthreads();
+    uint32_t rec_cnt = 0;
+    {
+        uint32_t my_base[CPT];
+#pragma unroll
+        for (uint32_t it = 0; it < CPT; ++it) my_base[it] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < CPT * NW; ++q) {
+            const uint32_t c = s_wcnt[q];
+#pragma unroll
+            for (uint32_t it = 0; it < CPT; ++it) my_base[it] += (q < it * NW + wave) ? c : 0u;
+            rec_cnt += c;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < CPT; ++it)
+            if ((lm[it] >> lane) & 1ull) {
+                const uint32_t pos = my_base[it] + (uint32_t)__popcll(lm[it] & ((1ull << lane) - 1ull));
+                if (pos < 256u) s_rec[pos] = mine[it];                      // (the plan only sends glyphs with <= 256 possible records)
+            }
+    }
+    rec_cnt = min(rec_cnt, 256u);
+    __syncthreads();
+
+    const float jscale = job.scale * 4.0f;
+    const float joff = (float)min_xs * 4.0f + (phase ? 0.5f : 0.0f) - 1.0f;
+    const float ncolf = (float)NCOL;
+    // every lane keeps the row ranges of its records in registers for all its bands: records RPL*lane ...
+    // (consecutive, so the record index grows along the pair sequence and the marker decode is a max-scan)
+    const bool few = rec_cnt <= 128u;              // workgroup-uniform: two records per lane are enough
+    uint32_t rra[4], rre[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (few ? 2u : 4u) * lane + (uint32_t)i;
+        const bool have = k < rec_cnt && (!few || i < 2);
+        const uint32_t f = s_rec[have ? k : 0u].fr;
+        rra[i] = have ? (f & 0x7ffu) : 1u;
+        rre[i] = have ? ((f >> 11) & 0x7ffu) : 0u;
+    }
+
+    uint16_t *s_lists = reinterpret_cast<uint16_t *>(wregion);
+    uint16_t *s_pairs = reinterpret_cast<uint16_t *>(wregion + L::OFF_PAIRS);
+    float *s_cy = reinterpret_cast<float *>(wregion + L::OFF_CY);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(wregion + L::OFF_CNT);
+    int16_t *s_roff = reinterpret_cast<int16_t *>(wregion + L::OFF_ROFF);
+    unsigned char *s_E = wregion;
+
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 5
+    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[1] + rra[2] + rre[3] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
+#endif
+    for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
+        const uint32_t band = band0 + wave;
+        if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
+        const uint32_t y0 = band * 16u;
+        const uint32_t row_b0 = band * 64u;
+        // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
+        const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane >> 2))) - sub_off((int)(lane & 3u), 4, phase)) / job.scale;
+        uint16_t *mylist = s_lists + lane * C4_LSTRIDE;
+        {
+            const uint4 ones = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
+#pragma unroll
+            for (uint32_t q = 0; q < CAP / 8u; ++q) c4_st16(mylist + 8u * q, ones);
+        }
+        s_cy[lane] = cy;
+        s_cnt[lane] = 0u;
+
+        // ---- layout + evaluation, in rounds of at most PCAP (record, row) pairs over a span of the band's rows
+        uint32_t rr0 = 0;                          // first row (in the band) not laid out yet
+        while (rr0 < 64u) {
+            uint32_t span = 64u - rr0;
+            uint32_t c[4], r0[4], csum, incl, tot;
+            for (;;) {
+                const uint32_t lo = row_b0 + rr0, hi = lo + span;
+                csum = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r0[i] = max(rra[i], lo);
+                    const uint32_t r1 = min(rre[i], hi);
+                    c[i] = r1 > r0[i] ? r1 - r0[i] : 0u;
+                    csum += c[i];
+                }
+                incl = c4_wave_incl_add(csum);
+                tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (tot <= (uint32_t)C4_PCAP || span == 1u) break;      // (one row has <= 256 pairs)
+                span >>= 1;
+            }
+            if (tot) {
+                // markers: slot `off` of the pair sequence holds k + 1 where record k's run starts, 0 elsewhere
+                if (C4_PCAP >= 512 || lane < C4_PCAP / 8) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
+                c4_wave_lds_sync();
+                uint32_t off = incl - csum;
+                uint32_t ro[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c[i]) s_pairs[off] = (uint16_t)((few ? 2u : 4u) * lane + (uint32_t)i + 1u);
+                    ro[i] = (r0[i] - row_b0 - off) & 0xffffu;
+                    off += c[i];
+                }
+                if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
+                else *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                c4_wave_lds_sync();
+                const uint32_t npairs = tot;
+                // one pair per lane per trip; the marker max-scan of the NEXT 64 pairs is issued before the
+                // current 64 are evaluated (an independent chain that fills the evaluation's wait states)
+                uint32_t k_cur = c4_wave_incl_max((uint32_t)s_pairs[lane]);
+                uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 3
+                for (uint32_t p0 = 0; p0 < npairs && A.n_jobs == 0xffffffffu; p0 += 64u) {     // timing-only: pairs laid out, never evaluated
+#else
+                for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
+#endif
+                    const uint32_t pn = min(p0 + 64u + lane, (uint32_t)C4_PCAP - 1u);
+                    const uint32_t s_next = c4_wave_incl_max((uint32_t)s_pairs[pn]);
+                    {
+                        const uint32_t p = p0 + lane, k1 = k_cur;
+                        const bool livep = p < npairs;
+                        // (a lane past the end decodes the last record and a row that may lie outside the band:
+                        // it computes like the others and is kept from the table walk and the append)
+                        const uint32_t row = ((uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u])) & 127u;
+                        const Rec40 r = *reinterpret_cast<const Rec40 *>(reinterpret_cast<const unsigned char *>(s_rec - 1) + __umul24(k1, (uint32_t)sizeof(Rec40)));
+                        const float cyr = s_cy[row & 63u];
+                        // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67);
+                        // the row range [ra, re) is exactly the set of rows on which the reference accepts this
+                        // root (fr_records.hpp), so its three rejection tests (:52, :59, :64) are not repeated
+                        const float delta = cyr * r.a + r.c1 - r.c2;
+                        const float sq = sqrt_rn(delta);
+                        const float numq = r.b + sq * r.sgn, numl = cyr - r.b;
+                        const unsigned long long linm = __builtin_amdgcn_sicmp((int32_t)r.fr, 0, 40 /* ICMP_SLT */);
+                        const float num = c4_self(linm, numl, numq);
+                        const float t = div_by_int(num, r.a, r.rden);
+                        const float xx = (r.ax * t + r.bx) * t + r.p0x;
+                        const float dy = r.a * t - r.b;
+                        const uint32_t cb = (r.fr >> 22) & 3u, zb = (r.fr >> 24) & 3u;
+                        const uint32_t code = (dy > 0.0f) ? zb : cb;
+                        // J = #{ j in [0, ncol) : cx(j) <= xx }   (:54, :66) — guess, one paired read, rare walk
+                        const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                        int J = (int)gf;
+                        {
+                            const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
+                            const bool good = (c0 <= xx) & (xx < c1);
+                            if (!good & livep) {
+                                while (s_cxp[J + 1] <= xx) ++J;
+                                while (s_cxp[J] > xx) --J;
+                            }
+                        }
+                        if (livep & (J > 0)) {
+                            const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
+                            uint16_t *rowlist = s_lists + __umul24(row, (uint32_t)C4_LSTRIDE);
+                            rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
+                        }
+                    }
+                    k_cur = max(s_next, carry);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+                }
+                c4_wave_lds_sync();
+            }
+            rr0 += span;
+        }
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 4
+        if (A.n_jobs != 0xffffffffu) continue;                                                  // timing-only: set-up, layout and evaluation alone
+#endif
+        const uint32_t cnt = s_cnt[lane];
+        uint8_t *const out_band = reinterpret_cast<uint8_t *>(A.out) + ((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s;
+        const uint32_t wx = lane & (NWIN - 1u);
+        if (__ballot(cnt != 0u) == 0ull) {
+            // no crossing on any of my 64 sample rows: every winding is 0 — store the band's background
+            for (uint32_t yl = lane >> WLOG; yl < 16u; yl += (64u >> WLOG)) {
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                __builtin_memcpy(out_band + (size_t)yl * A.out_stride + 16u * wx, &z, 16);
+            }
+            c4_wave_lds_sync();
+            continue;
+        }
+        // ---- pull my list into registers and sort it by J (network size = the wave's fullest row)
+        const bool ovf = cnt > (uint32_t)CAP;
+        uint32_t d[16];
+        uint32_t Hcur, maxcnt;
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 v = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
+                if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = c4_ld16(mylist + 8 * q);
+                d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+            }
+        }
+        const unsigned long long ovf_rows = __ballot(ovf);
+        if (ovf_rows) {
+            // over-full rows are settled by the direct sum below: their lists must add nothing
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d[q] = ovf ? 0xfffdfffdu : d[q];
+        }
+        if (CAP > 16 && __ballot(cnt > 16u && !ovf) != 0ull) {
+            c4_packed_sort<16>(d); Hcur = 16u;
+            maxcnt = __ballot(cnt > 28u) ? 32u : (__ballot(cnt > 24u) ? 28u : (__ballot(cnt > 20u) ? 24u : 20u));
+        } else if (CAP > 8 && __ballot(cnt > 8u && !ovf) != 0ull) {
+            c4_packed_sort<8>(d); Hcur = 8u;
+            maxcnt = __ballot(cnt > 12u) ? 16u : 12u;
+        } else {
+            c4_packed_sort<4>(d); Hcur = 4u;
+            maxcnt = __ballot(cnt > 4u) ? 8u : 4u;
+        }
+        c4_wave_lds_sync();                        // the list region becomes E below
+
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 6
+        if (A.n_jobs != 0xffffffffu) { if (d[0] + d[3] + d[7] + d[15] + Hcur + maxcnt == 0x12345u) s_cnt[0] = 1u; continue; }   // timing-only: up to the sort
+#endif
+        // ---- E: every byte starts at the bias 16
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(s_E);
+            const uint4 bias = make_uint4(0x10101010u, 0x10101010u, 0x10101010u, 0x10101010u);
+            constexpr uint32_t NZ = L::E / 16u;
+#pragma unroll
+            for (uint32_t q = 0; q < (NZ + 63u) / 64u; ++q)
+                if (NZ % 64u == 0u || lane + 64u * q < NZ) z[lane + 64u * q] = bias;
+        }
+        c4_wave_lds_sync();
+        // ---- toggles: right to left with the running winding; a crossing that changes zero <-> non-zero adds
+        // its two differences to my pixel row's bytes
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 2
+        if (A.n_jobs == 0xffffffffu)                                                            // timing-only: no toggles
+#endif
+        {
+            unsigned char *erow = s_E + (lane >> 2) * L::EROW;
+            int run = 0;
+            bool zero = true;
+            // toggles alternate (zero <-> non-zero), so -sigma of the next toggle is a register that flips:
+            // A = 255 * (-sigma), B = 4 * (-sigma); V = e0 + 256 e1 = -sigma (255 f + 4) = f A + B
+            int A255 = -255, B4 = -4, ns = -1;
+            auto slot = [&](uint32_t dw, int o) {       // crossing (J << 2) | code in bits o .. o + 15 of dw
+                run += (int)((dw >> o) & 3u) - 1;
+                const bool z = run == 0;
+                if (z != zero) {
+                    const uint32_t nib = (dw >> (o + 2)) & 15u;             // (P & 3) << 2 | f,  P = J >> 2, f = J & 3
+                    const int V = __mul24((int)(nib & 3u), A255) + B4;
+                    const uint32_t sh = (dw >> (o + 1)) & 0x18u;            // 8 (P & 3)
+                    uint32_t *dwp = reinterpret_cast<uint32_t *>(erow + ((dw >> (o + 4)) & 0xffcu));
+                    atomicAdd(dwp, (uint32_t)V << sh);
+                    // the second difference of a pixel in byte 3 belongs to the next dword: e1 = -sigma f
+                    // there, 0 elsewhere — f if (P & 3) == 3, i.e. nib - 12 saturated at 0
+                    const uint32_t g3 = __builtin_elementwise_sub_sat(nib, 12u);
+                    atomicAdd(dwp + 1, (uint32_t)__mul24((int)g3, ns));
+                    A255 = -A255; B4 = -B4; ns = -ns;
+                }
+                zero = z;
+            };
+#pragma unroll
+            for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
+                if ((uint32_t)(4 * gq) >= Hcur || Hcur + (uint32_t)(4 * gq) >= maxcnt) continue;     // wave-uniform
+#pragma unroll
+                for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(d[j], 16);
+            }
+#pragma unroll
+            for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
+                if ((uint32_t)(4 * gq) >= Hcur || (uint32_t)(4 * gq) >= maxcnt) continue;            // wave-uniform
+#pragma unroll
+                for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(d[j], 0);
+            }
+            // the row's constant: 4 [w(0) != 0], into byte 0 of the pixel row
+            if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), 4u);
+        }
+        if (ovf_rows) {
+            // ---- over-full sample rows: every stand-alone record of the glyph is evaluated once (lane = record,
+            // 64 at a time) and broadcast; lane L keeps the winding of sample columns 16 L ..., i.e. 4 pixels,
+            // and adds their inside counts to E in difference form (one dword of 4 bytes)
+            const Rec *grec = A.recs + 2u * (size_t)seg0;
+            const uint32_t n_all = A.glyph_rec_count[g];
+            unsigned long long todo = ovf_rows;
+            while (todo) {
+                const uint32_t r = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
+                int w16[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) w16[q] = 0;
+                for (uint32_t kb = 0; kb < n_all; kb += 64u) {
+                    const uint32_t k = kb + lane;
+                    bool ok = false;
+                    int J = 0, sgn = 0;
+                    if (k < n_all) {
+                        const Rec rk = grec[k];
+                        float xx;
+                        ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
+                        if (ok) {
+                            J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                            while (s_cxp[J + 1] <= xx) ++J;
+                            while (s_cxp[J] > xx) --J;
+                        }
+                    }
+                    unsigned long long m = __ballot(ok && J > 0);
+                    while (m) {
+                        const int i = (int)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        const uint32_t sJ = (uint32_t)__builtin_amdgcn_readlane(J, i);
+                        const int ss = __builtin_amdgcn_readlane(sgn, i);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) w16[q] += (16u * lane + (uint32_t)q < sJ) ? ss : 0;
+                    }
+                }
+                int cq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cq[q] = (w16[4 * q] != 0) + (w16[4 * q + 1] != 0) + (w16[4 * q + 2] != 0) + (w16[4 * q + 3] != 0);
+                int prev = __shfl_up(cq[3], 1);
+                if (lane == 0) prev = 0;
+                const uint32_t val = (uint32_t)(cq[0] - prev) + ((uint32_t)(cq[1] - cq[0]) << 8) +
+                                     ((uint32_t)(cq[2] - cq[1]) << 16) + ((uint32_t)(cq[3] - cq[2]) << 24);
+                if (16u * lane < NCOL) atomicAdd(reinterpret_cast<uint32_t *>(s_E + (r >> 2) * L::EROW) + lane, val);
+            }
+        }
+        c4_wave_lds_sync();
+
+        // ---- windows: lane = one 16-pixel window of one pixel row; integrate, map, one 16-byte store
+        constexpr uint32_t K1 = 0x01010101u;
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 1
+        if (A.n_jobs == 0xffffffffu)                                                            // timing-only: no windows, no stores
+#endif
+#pragma unroll
+        for (uint32_t it = 0; it < (16u * NWIN) / 64u; ++it) {
+            const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
+            const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
+            // inclusive byte prefix inside each dword: bytes 16 (i + 1) + sums; back to a bias of 16 per byte
+            uint32_t x0 = e.x * K1, x1 = e.y * K1, x2 = e.z * K1, x3 = e.w * K1;
+            x0 -= 0x30201000u;
+            x1 = x1 + __builtin_amdgcn_perm(x0, x0, 0x03030303u) - 0x40302010u;
+            x2 = x2 + __builtin_amdgcn_perm(x1, x1, 0x03030303u) - 0x40302010u;
+            x3 = x3 + __builtin_amdgcn_perm(x2, x2, 0x03030303u) - 0x40302010u;
+            // count entering my window = sum of the windows to my left in the pixel row
+            const uint32_t T = (x3 >> 24) - 16u;                            // my window's total (signed)
+            uint32_t inc = T;
+            if (WLOG == 4) {
+                inc += c4_dpp0<0x111>(inc);                                 // row_shr:1 within the 16 lanes of my pixel row
+                inc += c4_dpp0<0x112>(inc);
+                inc += c4_dpp0<0x114>(inc);
+                inc += c4_dpp0<0x118>(inc);
+            } else {
+                // 8 windows per pixel row: two pixel rows share a DPP row — keep the scan inside each half
+                uint32_t s;
+                s = c4_dpp0<0x111>(inc); inc += (wx >= 1u) ? s : 0u;
+                s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
+                s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u;
+            }
+            const uint32_t cin = inc - T;                                   // in [0, 16]
+            const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
+            x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 16 + k, k = inside samples of the pixel
+            // u8 = 16 k - [k > 8] = round_half_up(255 k / 16), four pixels at once (see the header)
+            auto map4 = [](uint32_t x) -> uint32_t {
+                const uint32_t t = ((x + 0x07070707u) >> 5) & 0x01010101u;
+                return (x << 4) + (0xfefeff00u - t);
+            };
+            const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
+            __builtin_memcpy(out_band + (size_t)prow * A.out_stride + 16u * wx, &v, 16);
+        }
+        c4_wave_lds_sync();                        // E is the next band's list region
+    }
+}
+
+size_t cov4_lds_bytes(int wlog) { return wlog == 4 ? C4Lds<4>::TOTAL : C4Lds<3>::TOTAL; }
+uint32_t cov4_wg_waves() { return C4_WAVES; }
+uint32_t cov4_max_segments() { return 256u; }
+
+template <int WLOG>
+static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
+{
+    const size_t lds = C4Lds<WLOG>::TOTAL + a.lds_pad;
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
+        return hipGetLastError();
+    };
+    if (a.kmax <= 8) return launch(cov4_kernel<WLOG, 8>);
+    if (a.kmax <= 16) return launch(cov4_kernel<WLOG, 16>);
+    return launch(cov4_kernel<WLOG, 32>);
+}
+
+// jobs: uniform cells (w a multiple of strip_w in {128, 256}, h a multiple of 16 and <= 256), 4 x 4 samples,
+// every glyph with <= 256 possible root records (checked by fr_plan_create)
+hipError_t launch_cov4(const RenderArgs &a, hipStream_t stream)
+{
+    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
+    if (a.strip_w == 256u) return cov4_launch_cap<4>(a, grid, stream);
+    if (a.strip_w == 128u) return cov4_launch_cap<3>(a, grid, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fr

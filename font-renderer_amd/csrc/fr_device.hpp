@@ -88,6 +88,8 @@ struct RenderArgs {
     const Rec *recs;
     const int16_t *pts;                // glyph points / per-segment p0 index: the render kernel builds its
     const uint32_t *seg_p0;            // glyph's records itself (in LDS) when `fused` is set
+    const int16_t *seg_pts;            // the same control points laid out per segment (6 x i16 each): cov4_kernel reads
+                                       // its segment with one load instead of two dependent ones
     uint32_t fused;
     uint32_t uniform;                  // every job: w a multiple of strip_w, h a multiple of the wave band (64/n rows)
     void *out;

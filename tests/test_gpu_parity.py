@@ -116,6 +116,112 @@ def test_coverage_stroke_dense(ctx, oracle, segs, cell):
     assert wref.max() >= 2          # overlapping strokes: non-zero fill is not even-odd here
 
 
+def _render_opt(ctx, gs, jobs, shape, n, center, **opts):
+    """one coverage render with context options set for its duration"""
+    defaults = {"cov4": 1, "kmax": 32, "min_wgs": 2048, "strip_px": 256}
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        dgs = fr.DeviceGlyphSet(ctx, gs)
+        got = np.full(shape, 7, np.uint8)
+        rg.render_batch(dgs, jobs, fr.FR_COVERAGE_U8, got, n, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+        dgs.close()
+    finally:
+        for k in opts:
+            ctx.set_option(k, defaults[k])
+    return got
+
+
+@pytest.mark.parametrize("cell,segs,center", [(256, 128, True), (256, 128, False), (128, 32, True), (128, 200, False), (256, 250, True)])
+def test_cov4_kernel_matches_the_oracle(ctx, oracle, cell, segs, center):
+    """cov4_kernel (fr_cov4.hip: coverage by integrating signed byte differences, 8-wave workgroups) on the
+    shapes it takes — 256- and 128-pixel cells, 16 samples per pixel, up to 256 segments — against the
+    oracle, and byte-identical to the general kernel on the same plan (ctx option cov4 = 0)."""
+    n_g = 6
+    gs = synth_glyphset(n_g, segs, first_index=500 + segs + cell)
+    jobs = cell_jobs(gs, cell, cell, 2048, 3)
+    shape = atlas_shape(n_g, cell, 3)
+    got = _render_opt(ctx, gs, jobs, shape, 4, center)
+    ref = np.full(shape, 7, np.uint8)
+    oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 4, center, 16)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, center, cov4=0), ref)
+    # bands split over workgroups (few jobs would not fill the chip) and kmax tiers (over-full rows by direct sum)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, center, min_wgs=1 << 20), ref)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, center, kmax=8), ref)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, center, kmax=16, min_wgs=1), ref)
+
+
+def test_cov4_kernel_strips_combs_strokes_and_mixed_plans(ctx, oracle):
+    """cov4_kernel: cells wider than one strip (512 x 64 px as two 256-px strips, 256 x 32 as two 128-px
+    strips), over-full rows (combs: 80 crossings per ray), stroke-dense glyphs, and a plan that mixes cells
+    it takes with cells it does not (odd sizes, > 256 segments): the job table is reordered inside the plan,
+    every cell still lands where its job says."""
+    # two strips per cell
+    gs = synth_glyphset(3, 64, first_index=880)
+    rows = [(i, int(np.floor(gs.boxes[i][0] * 0.25)), int(np.ceil(gs.boxes[i][3] * 0.25)) - 200, 512, 64, 0, 64 * i, np.float32(0.25)) for i in range(3)]
+    jobs = rg.make_jobs(rows)
+    ref = np.full((192, 512), 7, np.uint8)
+    oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 4, True, 16)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, (192, 512), 4, True), ref)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, (192, 512), 4, True, strip_px=128), ref)
+    assert ref.max() == 255
+    # combs and strokes
+    gl = []
+    for teeth in (40, 6):
+        cs, box = comb_glyph(teeth)
+        gl.append(Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs]))
+    sg = stroke_glyphset(4, 160, first_index=41)
+    gl += [sg.glyph(i) for i in range(len(sg))]
+    gs = GlyphSet(gl)
+    for cell in (128, 256):
+        jobs = cell_jobs(gs, cell, cell - 16, 2048, 3)
+        shape = atlas_shape(len(gs), cell, 3)
+        ref = np.full(shape, 7, np.uint8)
+        oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 4, True, 16)
+        for kmax in (32, 16, 8):
+            assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, True, kmax=kmax), ref), (cell, kmax)
+    # mixed plan
+    parts = [synth_glyphset(3, 100, first_index=21), synth_glyphset(2, 300, first_index=22), synth_glyphset(3, 256, first_index=23)]
+    gs = GlyphSet([p.glyph(i) for p in parts for i in range(len(p))])
+    jobs = cell_jobs(gs, 128, 128, 2048, 4).copy()
+    jobs["w"][1] = 125                      # not a whole strip: general kernel
+    jobs["h"][5] = 120                      # not a whole wave band
+    shape = atlas_shape(len(gs), 128, 4)
+    ref = np.full(shape, 7, np.uint8)
+    oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 4, True, 16)
+    assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, True), ref)
+
+
+def test_cov4_equals_general_kernel_on_2048_cells(ctx):
+    """2 048 glyphs x 256^2 (a tenth of configs[2]) through cov4_kernel and through the general kernel:
+    identical bytes (the general kernel is the one the oracle checks at small sizes)"""
+    import torch
+    G, cell, cols = 2048, 256, 32
+    gs = synth_glyphset(G, 128, first_index=100000)
+    jobs = cell_jobs(gs, cell, cell, 2048, cols)
+    H, W = atlas_shape(G, cell, cols)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    a = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    b = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    plan.render(a.data_ptr(), W, H)
+    ctx.sync()
+    plan.close()
+    try:
+        ctx.set_option("cov4", 0)
+        plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        plan.render(b.data_ptr(), W, H)
+        ctx.sync()
+        plan.close()
+    finally:
+        ctx.set_option("cov4", 1)
+    dgs.close()
+    assert torch.equal(a, b)
+    assert 0.2 < float((a > 0).float().mean()) < 0.8
+
+
 def test_ragged_cells_unaligned_output(ctx, oracle, ascii_set):
     """odd sizes, unaligned destinations, a stride that is not a multiple of 16"""
     gs = ascii_set.gs
