@@ -224,6 +224,8 @@ void cov4_kernel(const RenderArgs A)
     for (uint32_t it = 0; it < CPT; ++it) {
         const uint32_t c = tid + it * 64u * NW;
         bool live = false;
+        lm[it] = 0ull;
+        if (it > 0 && it * 64u * NW >= 2u * nseg) continue;                 // workgroup-uniform: no second candidate
         if (c < 2u * nseg) {                                                // (workgroup-uniform for it > 0: whole waves)
             Rec r;
             RowGeom geo;
@@ -256,6 +258,7 @@ void cov4_kernel(const RenderArgs A)
         for (uint32_t it = 0; it < CPT; ++it) my_base[it] = 0;
 #pragma unroll
         for (uint32_t q = 0; q < CPT * NW; ++q) {
+            if (q >= NW && q / NW * 64u * NW >= 2u * nseg) continue;        // (never written)
             const uint32_t c = s_wcnt[q];
 #pragma unroll
             for (uint32_t it = 0; it < CPT; ++it) my_base[it] += (q < it * NW + wave) ? c : 0u;
@@ -365,8 +368,10 @@ void cov4_kernel(const RenderArgs A)
                         const bool livep = p < npairs;
                         // (a lane past the end decodes the last record and a row that may lie outside the band:
                         // it computes like the others and is kept from the table walk and the append)
-                        const uint32_t row = ((uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u])) & 127u;
-                        const Rec40 r = *reinterpret_cast<const Rec40 *>(reinterpret_cast<const unsigned char *>(s_rec - 1) + __umul24(k1, (uint32_t)sizeof(Rec40)));
+                        const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u]);
+                        // (one 24-bit multiply-add for the record's LDS address, small offsets for its five 8-byte reads)
+                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
+                        const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
                         const float cyr = s_cy[row & 63u];
                         // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67);
                         // the row range [ra, re) is exactly the set of rows on which the reference accepts this
@@ -393,8 +398,8 @@ void cov4_kernel(const RenderArgs A)
                             }
                         }
                         if (livep & (J > 0)) {
-                            const uint32_t pos = atomicAdd(&s_cnt[row], 1u);
-                            uint16_t *rowlist = s_lists + __umul24(row, (uint32_t)C4_LSTRIDE);
+                            const uint32_t pos = atomicAdd(&s_cnt[row & 63u], 1u);
+                            uint16_t *rowlist = s_lists + __umul24(row & 63u, (uint32_t)C4_LSTRIDE);
                             rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
                         }
                     }
@@ -594,7 +599,10 @@ void cov4_kernel(const RenderArgs A)
             // u8 = 16 k - [k > 8] = round_half_up(255 k / 16), four pixels at once (see the header)
             auto map4 = [](uint32_t x) -> uint32_t {
                 const uint32_t t = ((x + 0x07070707u) >> 5) & 0x01010101u;
-                return (x << 4) + (0xfefeff00u - t);
+                const uint32_t u = 0xfefeff00u - t;
+                uint32_t r;
+                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(r) : "v"(x), "v"(u));      // (x << 4) + u in one instruction
+                return r;
             };
             const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
             __builtin_memcpy(out_band + (size_t)prow * A.out_stride + 16u * wx, &v, 16);
