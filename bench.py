@@ -30,6 +30,19 @@ WORKLOADS = {
     "c4_bmp_shard_128px_s32_16spp": dict(glyphs=7936, cell=128, segs=32, n=4, cols=64),
     # BASELINE.json configs[4] per-GPU share (4 096 glyphs / 8 = 512, 512^2 cells): build-defined SDF, 1 sample
     "c5_sdf_shard_512px_s64": dict(glyphs=512, cell=512, segs=64, n=1, cols=16, mode="sdf"),
+    # SURVEY §8(d) segment list {16, 32, 64, 128, 256}: the C3 shape at the other segment counts
+    "c3_cjk21k_256px_s256_16spp": dict(glyphs=20992, cell=256, segs=256, n=4, cols=64),
+    "c3_cjk21k_256px_s64_16spp": dict(glyphs=20992, cell=256, segs=64, n=4, cols=64),
+    "c3_cjk21k_256px_s16_16spp": dict(glyphs=20992, cell=256, segs=16, n=4, cols=64),
+    # stroke-dense outlines: 8-16 thin strokes per glyph, 10-30 crossings per ray (synth.stroke_glyph)
+    "c3_strokes21k_256px_s128_16spp": dict(glyphs=20992, cell=256, segs=128, n=4, cols=64, gen="stroke"),
+    # a real font through the C-side contour producer (fr_font_*): every glyph of DejaVuSerif-Italic the reference
+    # could load (~3 000, up to 347 segments), 4 sizes each -> 256^2 cells
+    "real_dejavuserif_italic_whole_font_256px_16spp": dict(glyphs=0, cell=256, segs=0, n=4, cols=64, gen="font",
+                                                           font="/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"),
+    # the reference's own products (one sample per pixel, the pixel corner): renderGlyph's value map and Image.Winding
+    "c3_cjk21k_256px_s128_gray_debug": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="gray_debug"),
+    "c3_cjk21k_256px_s128_winding_i16": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="winding_i16"),
 }
 
 

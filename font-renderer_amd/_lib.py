@@ -40,6 +40,7 @@ _I16P, _U32P, _U8P = C.POINTER(C.c_int16), C.POINTER(C.c_uint32), C.POINTER(C.c_
 SYMBOLS = [
     ("fr_abi_version", C.c_int, []),
     ("fr_last_error", C.c_char_p, []),
+    ("fr_build_id", C.c_char_p, []),
     ("fr_ctx_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     ("fr_ctx_destroy", None, [_P]),
     ("fr_ctx_sync", C.c_int, [_P]),
@@ -53,6 +54,7 @@ SYMBOLS = [
     ("fr_plan_render", C.c_int, [_P, _P, C.c_size_t, C.c_size_t]),
     ("fr_plan_render_timed", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     ("fr_plan_pixels", C.c_uint64, [_P]),
+    ("fr_plan_stats", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fr_render_batch", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(RasterParams), _P, C.c_size_t, C.c_size_t]),
     ("fr_render_glyph_dims", C.c_int, [_P, C.c_uint16, C.c_uint16, _P, _P, C.POINTER(C.c_uint16),
                                        C.POINTER(C.c_uint16), C.POINTER(C.c_float)]),
@@ -60,6 +62,9 @@ SYMBOLS = [
     ("fr_glyph_info_init", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     ("fr_winding_in_glyph", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P]),
     ("fr_winding_lattice", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
+    ("fr_glyph_debug_render", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint8, _P]),
+    ("fr_atlas_layout", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  _P, _P, C.POINTER(C.c_uint32)]),
     ("fr_exact_lattice", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, _P]),
     ("fr_exact_coverage", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("fr_font_open", C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),

@@ -23,13 +23,14 @@ uint32_t render_wg_waves();
 hipError_t launch_cov4(const RenderArgs &, hipStream_t);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
-hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
+hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, int cull, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, int, uint8_t *,
                        uint8_t *, hipStream_t);
 void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
                           uint32_t, const int16_t *, uint64_t, uint32_t, int, int, int, int16_t *,
                           hipStream_t);
 void launch_exact_cover(const int16_t *, uint32_t, uint32_t, uint32_t, uint8_t *, hipStream_t);
+void launch_glyph_debug_color(const int16_t *, uint64_t, uint32_t, uint32_t, uint8_t *, hipStream_t);
 }  // namespace fr
 
 static_assert(sizeof(fr_job) == sizeof(fr::Job), "fr_job layout");
@@ -74,6 +75,12 @@ struct fr_ctx {
     uint32_t lds_pad = 0;        // experiment knob: extra dynamic LDS bytes per workgroup (occupancy studies)
     uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
     uint32_t cov4 = 1;           // 16-sample coverage of uniform cells takes cov4_kernel (fr_cov4.hip) where it fits
+    uint32_t sdf_cull = 1;       // FR_SDF_U8: drop segments that cannot change a tile / a pixel (exact; 0 = look at all, for tests)
+    // scratch of the single-glyph entry point (fr_render_glyph): one device arena and one host staging
+    // buffer, grown on demand and reused across calls
+    unsigned char *arena = nullptr;
+    size_t arena_cap = 0;
+    std::vector<unsigned char> stage;
 };
 
 struct fr_glyphset {
@@ -113,6 +120,7 @@ extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_last_error(void) { return g_err; }
+const char *fr_build_id(void) { return "r02.3-cov4"; }
 
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
 {
@@ -144,6 +152,7 @@ void fr_ctx_destroy(fr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -171,6 +180,7 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "fuse_prepare")) { ctx->fuse_prepare = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
     if (!strcmp(key, "cov4")) { ctx->cov4 = value ? 1u : 0u; return FR_OK; }
+    if (!strcmp(key, "sdf_cull")) { ctx->sdf_cull = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "min_wgs")) {
         if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
         ctx->min_wgs = (uint32_t)value;
@@ -474,6 +484,14 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
 
 uint64_t fr_plan_pixels(const fr_plan *plan) { return plan ? plan->pixels : 0; }
 
+int fr_plan_stats(const fr_plan *plan, uint32_t *n_jobs_cov4, uint32_t *n_jobs_general)
+{
+    if (!plan) return fail(FR_E_INVALID, "fr_plan_stats: NULL");
+    if (n_jobs_cov4) *n_jobs_cov4 = plan->n_fast;
+    if (n_jobs_general) *n_jobs_general = plan->n_jobs - plan->n_fast;
+    return FR_OK;
+}
+
 static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
 {
     if (!plan) return fail(FR_E_INVALID, "plan is NULL");
@@ -535,7 +553,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
             // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,
             // same sample points) lands in the output; the distance kernel reads it and overwrites it
             HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
-            HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, plan->ctx->stream));
+            HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, (int)plan->ctx->sdf_cull, plan->ctx->stream));
             return FR_OK;
         }
         HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
@@ -611,6 +629,11 @@ int fr_render_glyph_dims(const int16_t box[4], uint16_t units_per_em, uint16_t f
     return FR_OK;
 }
 
+// One glyph, one image — the reference's call shape.  No allocation per call: the glyph tables, the job and the
+// output live in the context's device arena (grown on demand), filled by ONE host-to-device copy of a packed
+// staging buffer; the render kernel builds the root records in LDS (prepare_kernel runs only for a glyph of
+// more than 128 segments); the image comes back with one device-to-host copy.  The job covers the whole image,
+// so the caller's buffer is never uploaded.
 int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                     uint32_t n_contours, const int16_t box[4], uint16_t units_per_em,
                     uint16_t font_size, int32_t mode, void *out_host)
@@ -621,18 +644,79 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
     float scale;
     int rc = fr_render_glyph_dims(box, units_per_em, font_size, mn, mx, &w, &h, &scale);
     if (rc) return rc;
-    const uint32_t gstart[2] = {0, n_contours};
-    const uint32_t zero_start[1] = {0};
-    fr_glyphset *gs = nullptr;
-    rc = fr_glyphset_create(ctx, points_xy, n_contours ? contour_start : zero_start, n_contours, gstart, 1, &gs);
-    if (rc) return rc;
-    fr_job jb{};
-    jb.glyph = 0; jb.min_x = mn[0]; jb.max_y = mx[1]; jb.w = w; jb.h = h; jb.out_x = 0; jb.out_y = 0; jb.scale = scale;
     fr_raster_params prm{};
     prm.mode = mode; prm.samples_per_axis = 1; prm.sample_phase = FR_SAMPLE_CORNER;
-    rc = fr_render_batch(ctx, gs, &jb, 1, &prm, out_host, w, h);
-    fr_glyphset_destroy(gs);
-    return rc;
+    rc = check_params(&prm);
+    if (rc) return rc;
+    if (!out_host) return fail(FR_E_INVALID, "out_host is NULL");
+    const uint32_t zero_start[1] = {0};
+    std::vector<uint32_t> seg_p0, seg_prev;
+    uint64_t np = 0;
+    rc = flatten_segments(n_contours ? contour_start : zero_start, n_contours, &np, seg_p0, seg_prev, nullptr);
+    if (rc) return rc;
+    if (np && !points_xy) return fail(FR_E_INVALID, "points_xy is NULL");
+    const uint32_t ns = (uint32_t)seg_p0.size();
+    if (scale < 9.5367431640625e-07f || scale > 1048576.0f) return fail(FR_E_UNSUPPORTED, "scale outside [2^-20, 2^20]");
+    fr_job jb{};
+    jb.glyph = 0; jb.min_x = mn[0]; jb.max_y = mx[1]; jb.w = w; jb.h = h; jb.out_x = 0; jb.out_y = 0; jb.scale = scale;
+    // arena layout (every part 16-byte aligned); the first `up` bytes are uploaded
+    auto al = [](size_t v) { return (v + 15u) & ~(size_t)15; };
+    const size_t esz = mode == FR_WINDING_I16 ? 2 : 1;
+    const size_t o_pts = 0, o_p0 = al(o_pts + np * 4 + 16), o_spts = al(o_p0 + (size_t)ns * 4 + 4);
+    const size_t o_gseg = al(o_spts + (size_t)ns * 12 + 16), o_job = al(o_gseg + 8), o_jseg = al(o_job + sizeof(fr_job));
+    const size_t o_large = al(o_jseg + 8), up = al(o_large + 4);
+    const size_t o_cnt = up, o_recs = al(o_cnt + 8), o_out = al(o_recs + (size_t)(ns ? ns : 1) * 2 * sizeof(fr::Rec));
+    const size_t total = al(o_out + (size_t)w * h * esz);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (total > ctx->arena_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) { (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_cap = 0; }
+        const size_t cap = std::max<size_t>(total + total / 2, 1u << 20);
+        HIP_TRY(hipMalloc(&ctx->arena, cap));
+        ctx->arena_cap = cap;
+    }
+    ctx->stage.assign(up, 0);
+    unsigned char *st = ctx->stage.data();
+    if (np) memcpy(st + o_pts, points_xy, np * 4);
+    if (ns) memcpy(st + o_p0, seg_p0.data(), (size_t)ns * 4);
+    for (uint32_t sgi = 0; sgi < ns; ++sgi) memcpy(st + o_spts + 12u * (size_t)sgi, points_xy + 2u * (size_t)seg_p0[sgi], 12);
+    const uint32_t gseg[2] = {0, ns}, jseg[2] = {0, ns}, large0[1] = {0};
+    memcpy(st + o_gseg, gseg, 8); memcpy(st + o_job, &jb, sizeof jb); memcpy(st + o_jseg, jseg, 8); memcpy(st + o_large, large0, 4);
+    unsigned char *A0 = ctx->arena;
+    HIP_TRY(hipMemcpyAsync(A0, st, up, hipMemcpyHostToDevice, ctx->stream));
+    // views of the arena dressed as a glyph set and a plan (nothing here owns memory: never destroyed)
+    fr_glyphset gs;
+    gs.ctx = ctx; gs.n_glyphs = 1; gs.n_contours = n_contours; gs.n_seg = ns; gs.max_seg_per_glyph = ns; gs.n_points = np;
+    gs.d_pts = reinterpret_cast<int16_t *>(A0 + o_pts); gs.d_seg_pts = reinterpret_cast<int16_t *>(A0 + o_spts);
+    gs.d_seg_p0 = reinterpret_cast<uint32_t *>(A0 + o_p0); gs.d_glyph_seg_start = reinterpret_cast<uint32_t *>(A0 + o_gseg);
+    gs.d_rec_count = reinterpret_cast<uint32_t *>(A0 + o_cnt); gs.d_recs = reinterpret_cast<fr::Rec *>(A0 + o_recs);
+    fr_plan pl;
+    pl.ctx = ctx; pl.gs = &gs; pl.n_jobs = 1; pl.n_fast = 0; pl.params = prm;
+    pl.d_jobs = reinterpret_cast<fr::Job *>(A0 + o_job); pl.d_job_seg = reinterpret_cast<uint32_t *>(A0 + o_jseg);
+    pl.d_large = reinterpret_cast<uint32_t *>(A0 + o_large); pl.n_large = ns > 128u ? 1u : 0u;
+    pl.max_w = w; pl.max_h = h; pl.pixels = (uint64_t)w * h; pl.need_cols = w; pl.need_rows = h;
+    uint32_t sw = ((uint32_t)w + 15u) & ~15u;
+    if (sw > ctx->strip_px) sw = ctx->strip_px;
+    pl.strip_w = sw;
+    pl.bands = pl.gen_bands = ((uint32_t)h + 63u) / 64u;
+    pl.strips = pl.gen_strips = ((uint32_t)w + sw - 1u) / sw;
+    pl.uniform = false;
+    int lrc = FR_OK;
+    if (mode == FR_SDF_U8 || pl.n_large) {
+        // the stand-alone records (float brackets): the staged path of a large glyph and the SDF's stand-alone users
+        hipError_t e = hipMemsetAsync(gs.d_rec_count, 0, 8, ctx->stream);
+        if (e != hipSuccess) lrc = fail(FR_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    if (lrc == FR_OK) lrc = plan_launch(&pl, A0 + o_out, w, h);
+    hipError_t e = hipSuccess;
+    if (lrc == FR_OK) e = hipMemcpyAsync(out_host, A0 + o_out, (size_t)w * h * esz, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    gs.d_pts = gs.d_seg_pts = nullptr; gs.d_seg_p0 = gs.d_glyph_seg_start = gs.d_rec_count = nullptr; gs.d_recs = nullptr;
+    pl.d_jobs = nullptr; pl.d_job_seg = nullptr; pl.d_large = nullptr;
+    if (lrc) return lrc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return fail(FR_E_HIP, "fr_render_glyph: %s", hipGetErrorString(e));
+    return FR_OK;
 }
 
 // ---- exact-integer path ---------------------------------------------------
@@ -781,6 +865,85 @@ int fr_exact_coverage(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *con
     rc = exact_setup(ctx, points_xy, contour_start, n_contours, d, (int)K);
     if (rc) return rc;
     return exact_run(ctx, d, nullptr, (uint64_t)w_px * n * h_px * n, w_px * n, x0, y0, out_host, w_px, h_px, n);
+}
+
+
+int fr_glyph_debug_render(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                          uint32_t n_contours, const int16_t box[4], uint8_t winding_scale, uint8_t *rgb_host)
+{
+    if (!box) return fail(FR_E_INVALID, "box is NULL");
+    if (!rgb_host) return fail(FR_E_INVALID, "rgb_host is NULL");
+    const int W = (int)box[2] - box[0] + 3, H = (int)box[3] - box[1] + 3;       // Image.zig:183
+    if (W < 1 || H < 1) return fail(FR_E_INVALID, "empty box");
+    ExactDev d;
+    int rc = exact_setup(ctx, points_xy, contour_start, n_contours, d);
+    if (rc) return rc;
+    const uint64_t nq = (uint64_t)W * H;
+    int16_t *d_lat = nullptr;
+    uint8_t *d_rgb = nullptr;
+    hipError_t e = hipMalloc(&d_lat, nq * 2);
+    if (e == hipSuccess) e = hipMalloc(&d_rgb, nq * 3);
+    if (e == hipSuccess) {
+        // the lattice GlyphDebug.render walks (Image.zig:227-236), coloured on the device (setWindingLinear)
+        fr::launch_exact_winding(d.pts, d.seg_p0, d.ctype, d.inc, d.n_seg, nullptr, nq, (uint32_t)W, box[0] - 1, box[3] + 1, 1, d_lat, ctx->stream);
+        fr::launch_glyph_debug_color(d_lat, nq, winding_scale, 150u, d_rgb, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb_host, d_rgb, nq * 3, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = e2;
+    dfree(d_lat); dfree(d_rgb);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FR_E_NOMEM : FR_E_HIP, "fr_glyph_debug_render: %s", hipGetErrorString(e));
+    // setGlyphPoints (Image.zig:202-218): a few writes in the reference's own order (later points overwrite
+    // earlier ones where they coincide), done on the host on the image just copied back
+    for (uint32_t c = 0; c < n_contours; ++c) {
+        const int16_t *cp = points_xy + 2u * (size_t)contour_start[c];
+        const uint32_t curves = (contour_start[c + 1] - contour_start[c]) / 2u;
+        for (uint32_t k = 0; k < curves; ++k) {
+            for (int which = 0; which < 2; ++which) {
+                const int16_t *pt = cp + 2u * (2u * k + (uint32_t)which);
+                const int64_t wq = (int64_t)pt[0] - box[0] + 1, hq = (int64_t)box[3] - pt[1] + 1;
+                if (wq < 0 || hq < 0 || wq >= W || hq >= H)
+                    return fail(FR_E_INVALID, "glyph point outside its box (the reference would write out of bounds)");
+                uint8_t *px = rgb_host + 3u * ((size_t)hq * W + (size_t)wq);
+                if (which == 0) { px[0] = 255; px[1] = 255; px[2] = 0; }        // on-curve
+                else { px[0] = 0; px[1] = 255; px[2] = 255; }                   // control
+            }
+        }
+    }
+    return FR_OK;
+}
+
+int fr_atlas_layout(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyph,
+                    const uint16_t *units_per_em, uint32_t n_upm, uint16_t font_size,
+                    uint32_t cell, uint32_t cols, uint32_t rows_per_page,
+                    fr_job *jobs_out, uint32_t *page_of_job, uint32_t *n_pages)
+{
+    if (n_glyphs && (!boxes || !jobs_out)) return fail(FR_E_INVALID, "fr_atlas_layout: NULL argument");
+    if (!units_per_em || (n_upm != 1 && n_upm != n_glyphs)) return fail(FR_E_INVALID, "units_per_em: one value or one per glyph");
+    if (cell == 0 || cols == 0 || font_size == 0) return fail(FR_E_INVALID, "cell, cols and font_size must be > 0");
+    if ((uint64_t)cell * cols > 0xffffffffull) return fail(FR_E_UNSUPPORTED, "atlas wider than 2^32 pixels");
+    const uint64_t per_page = rows_per_page ? (uint64_t)rows_per_page * cols : 0;
+    for (uint32_t i = 0; i < n_glyphs; ++i) {
+        const uint16_t upm = units_per_em[n_upm == 1 ? 0 : i];
+        if (upm == 0) return fail(FR_E_INVALID, "units_per_em must be > 0");
+        const float scale = (float)font_size / (float)upm;                              // render_glyph.zig:13
+        const float fx = std::floor((float)boxes[4 * (size_t)i + 0] * scale);           // :15-16
+        const float fy = std::ceil((float)boxes[4 * (size_t)i + 3] * scale);            // :15, :17
+        const uint64_t slot = per_page ? i % per_page : i;
+        const uint64_t row = slot / cols;
+        if (row * cell > 0xffffffffull) return fail(FR_E_UNSUPPORTED, "atlas taller than 2^32 pixels: use pages");
+        fr_job &jb = jobs_out[i];
+        jb.glyph = first_glyph + i;
+        jb.min_x = (int32_t)fx; jb.max_y = (int32_t)fy;
+        jb.w = cell; jb.h = cell;
+        jb.out_x = (uint32_t)(slot % cols) * cell;
+        jb.out_y = (uint32_t)row * cell;
+        jb.scale = scale;
+        if (page_of_job) page_of_job[i] = per_page ? (uint32_t)(i / per_page) : 0u;
+    }
+    if (n_pages) *n_pages = per_page ? (uint32_t)((n_glyphs + per_page - 1) / per_page) : (n_glyphs ? 1u : 0u);
+    return FR_OK;
 }
 
 }  // extern "C"

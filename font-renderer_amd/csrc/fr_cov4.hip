@@ -193,7 +193,6 @@ void cov4_kernel(const RenderArgs A)
     constexpr uint32_t SW = 16u << WLOG;            // strip width, pixels
     constexpr uint32_t NCOL = SW * 4u;              // sample columns
     constexpr uint32_t NWIN = 1u << WLOG;           // 16-pixel windows per pixel row
-    constexpr uint32_t EMPTY = 0xfffdu;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -207,7 +206,6 @@ void cov4_kernel(const RenderArgs A)
     if (band_first * 16u >= job.h || x0s >= job.w) return;                  // workgroup-uniform
     const uint32_t band_end = min(band_first + A.bands_per_wg, job.h / 16u);
     const int phase = A.phase_center;
-    const uint32_t g = job.glyph;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
 
     float *s_cxp = reinterpret_cast<float *>(smem);
@@ -513,16 +511,16 @@ void cov4_kernel(const RenderArgs A)
             if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), 4u);
         }
         if (ovf_rows) {
-            // ---- over-full sample rows: every stand-alone record of the glyph is evaluated once (lane = record,
-            // 64 at a time) and broadcast; lane L keeps the winding of sample columns 16 L ..., i.e. 4 pixels,
-            // and adds their inside counts to E in difference form (one dword of 4 bytes)
-            const Rec *grec = A.recs + 2u * (size_t)seg0;
-            const uint32_t n_all = A.glyph_rec_count[g];
+            // ---- over-full sample rows: every record of the glyph (in LDS, with its exact row range) is evaluated
+            // once (lane = record, 64 at a time) and broadcast; lane L keeps the winding of sample columns
+            // 16 L ..., i.e. 4 pixels, and adds their inside counts to E in difference form (one dword of 4 bytes)
+            const uint32_t n_all = rec_cnt;
             unsigned long long todo = ovf_rows;
             while (todo) {
                 const uint32_t r = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
+                const uint32_t grow = row_b0 + r;
                 int w16[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) w16[q] = 0;
@@ -531,10 +529,16 @@ void cov4_kernel(const RenderArgs A)
                     bool ok = false;
                     int J = 0, sgn = 0;
                     if (k < n_all) {
-                        const Rec rk = grec[k];
-                        float xx;
-                        ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
+                        const Rec40 rk = s_rec[k];
+                        ok = grow >= (rk.fr & 0x7ffu) && grow < ((rk.fr >> 11) & 0x7ffu);    // the rows that accept this root
                         if (ok) {
+                            const bool lin = (int32_t)rk.fr < 0;
+                            const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                            const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                            const float t = div_by_int(num, rk.a, rk.rden);
+                            const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                            const float dy = rk.a * t - rk.b;
+                            sgn = (int)((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1;
                             J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
                             while (s_cxp[J + 1] <= xx) ++J;
                             while (s_cxp[J] > xx) --J;

@@ -260,6 +260,30 @@ void launch_exact_cover(const int16_t *wind, uint32_t w_px, uint32_t h_px, uint3
     hipLaunchKernelGGL(exact_cover_kernel, dim3((uint32_t)((nq + 255u) / 256u)), dim3(256), 0, stream, wind, w_px, h_px, n, out);
 }
 
+// Image.GlyphDebug.setWindingLinear (Image.zig:192-200): one RGB triple per lattice point —
+//   c = |winding| *| scale (u16 saturating multiply); main = min(c, 255); sub = (c == main) ? 0 : overflow;
+//   winding > 0: {sub, sub, main} (blue) else {main, sub, sub} (red; winding == 0 gives {0, 0, 0} either way)
+__global__ __launch_bounds__(256) void glyph_debug_color_kernel(const int16_t *__restrict__ wind, uint64_t n,
+                                                                uint32_t scale, uint32_t overflow, uint8_t *__restrict__ rgb)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (q >= n) return;
+    const int v = wind[q];
+    uint32_t c = (uint32_t)(v < 0 ? -v : v) * scale;
+    if (c > 65535u) c = 65535u;
+    const uint32_t mainc = c > 255u ? 255u : c, sub = (c == mainc) ? 0u : overflow;
+    uint8_t *d = rgb + 3u * q;
+    d[0] = (uint8_t)(v > 0 ? sub : mainc);
+    d[1] = (uint8_t)sub;
+    d[2] = (uint8_t)(v > 0 ? mainc : sub);
+}
+
+void launch_glyph_debug_color(const int16_t *wind, uint64_t n, uint32_t scale, uint32_t overflow, uint8_t *rgb, hipStream_t stream)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(glyph_debug_color_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, wind, n, scale, overflow, rgb);
+}
+
 void launch_exact_winding(const int16_t *pts, const uint32_t *seg_p0, const uint8_t *ctype,
                           const uint8_t *inc_p0, uint32_t n_seg, const int16_t *queries,
                           uint64_t n_query, uint32_t lat_w, int lat_x0, int lat_y0, int K, int16_t *out,

@@ -622,7 +622,10 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
     // sum: every record of the glyph (the stand-alone records in HBM: all of them, whatever sits in LDS) is
     // evaluated once — lane = record, 64 at a time — and broadcast with v_readlane to all lanes
     auto row_windings = [&](uint32_t br, int (&w16)[16]) {
-        const uint32_t n_all = A.glyph_rec_count[g];
+        // fused job: the records are in LDS, each with the exact range of sample rows that accept it;
+        // otherwise the stand-alone records in HBM (all of them, whatever chunk sits in LDS), with their brackets
+        const uint32_t n_all = fused ? rec_cnt : A.glyph_rec_count[g];
+        const uint32_t grow = row_b0 + br;          // sample row in the cell
         const uint32_t col0 = 16u * lane;
         const float cy_r = bcast(cy, br);
 #pragma unroll
@@ -632,9 +635,17 @@ __global__ __launch_bounds__(64 * FR_WG_WAVES) FR_OCC void render_kernel(const R
             bool ok = false;
             int J = 0, sgn = 0;
             if (k < n_all) {
-                const Rec rk = grec[k];
+                Rec rk;
+                bool in_range;
+                if (fused) {
+                    rk = s_rec[k];
+                    in_range = grow >= __builtin_bit_cast(uint32_t, rk.lo) && grow < __builtin_bit_cast(uint32_t, rk.hi);
+                } else {
+                    rk = grec[k];
+                    in_range = cy_r >= rk.lo && cy_r <= rk.hi;
+                }
                 float xx;
-                ok = cy_r >= rk.lo && cy_r <= rk.hi && rec_cross(rk, cy_r, xx, sgn);
+                ok = in_range && rec_cross(rk, cy_r, xx, sgn);
                 if (ok) {       // J = #{ j : cx(j) <= xx }, as in the evaluation pass
                     J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
                     while (s_cxp[J + 1] <= xx) ++J;

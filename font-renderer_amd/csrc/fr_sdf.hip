@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
                                                   const uint32_t *__restrict__ glyph_rec_count,
                                                   const Rec *__restrict__ recs, uint8_t *__restrict__ out,
                                                   uint64_t out_stride, uint32_t tiles_x, uint32_t tiles_y,
-                                                  int phase_center)
+                                                  int phase_center, int cull)
 {
     __shared__ float s_seg[256][10];            // p0, p1, p2 and the control-point box (x0, x1, y0, y1)
     __shared__ uint32_t s_n;
@@ -87,8 +87,15 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
     const float tqx1 = ((float)(job.min_x + (int32_t)(tx * 16u + 15u)) + off) / job.scale;
     const float tqy1 = ((float)(job.max_y - (int32_t)(ty * 16u)) - off) / job.scale;
     const float tqy0 = ((float)(job.max_y - (int32_t)(ty * 16u + 15u)) - off) / job.scale;
-    // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding
-    const float reach = 8.0f / job.scale * 1.02f + 1.0f;
+    // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding.
+    // cull == 0 (ctx option "sdf_cull", tests): no segment is ever dropped or skipped
+    const float reach = cull ? 8.0f / job.scale * 1.02f + 1.0f : 3.0e+37f;
+    // A computed curve point B(t) - q can leave the control-point box by a few roundings of its three-term sum
+    // (each <= half an ulp of a magnitude <= 2^18 for i16 points: < 2^-6 font units, far less relative to a
+    // distant sample).  The boxes the culls look at are therefore grown by `slack`, so that "the computed
+    // distance is >= the box distance" holds for the ROUNDED distance too and a skipped segment can never have
+    // produced a smaller value — whatever order the segments were staged in.
+    const float slack = 0.25f + 1.0e-6f * (fabsf(qx) + fabsf(qy));
     float best = 3.402823466e+38f;
     for (uint32_t base = s0; base < s1; base += 256u) {
         if (threadIdx.x == 0) s_n = 0u;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
             const float hx0 = fminf(fminf(c[0], c[2]), c[4]), hx1 = fmaxf(fmaxf(c[0], c[2]), c[4]);
             const float hy0 = fminf(fminf(c[1], c[3]), c[5]), hy1 = fmaxf(fmaxf(c[1], c[3]), c[5]);
             const float gx = fmaxf(fmaxf(hx0 - tqx1, tqx0 - hx1), 0.0f), gy = fmaxf(fmaxf(hy0 - tqy1, tqy0 - hy1), 0.0f);
-            if (gx * gx + gy * gy <= reach * reach) {
+            if (!cull || gx * gx + gy * gy <= reach * reach) {
                 const uint32_t slot = atomicAdd(&s_n, 1u);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) s_seg[slot][k] = c[k];
@@ -115,10 +122,10 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
             for (uint32_t k = 0; k < n; ++k) {
                 // per pixel the same argument: the computed distance is >= the distance to the segment's box,
                 // so a box no nearer than the best so far (or than the saturation reach) changes nothing
-                const float gx = fmaxf(fmaxf(s_seg[k][6] - qx, qx - s_seg[k][7]), 0.0f);
-                const float gy = fmaxf(fmaxf(s_seg[k][8] - qy, qy - s_seg[k][9]), 0.0f);
+                const float gx = fmaxf(fmaxf(s_seg[k][6] - qx, qx - s_seg[k][7]) - slack, 0.0f);
+                const float gy = fmaxf(fmaxf(s_seg[k][8] - qy, qy - s_seg[k][9]) - slack, 0.0f);
                 const float g2 = gx * gx + gy * gy;
-                if (g2 >= best || g2 > reach * reach) continue;
+                if (cull && (g2 >= best || g2 > reach * reach)) continue;
                 const float d2 = seg_dist2(s_seg[k][0], s_seg[k][1], s_seg[k][2], s_seg[k][3], s_seg[k][4], s_seg[k][5], qx, qy);
                 if (d2 < best) best = d2;
             }
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, 
 }
 
 hipError_t launch_sdf(const RenderArgs &a, const int16_t *pts, const uint32_t *seg_p0, uint32_t max_w,
-                      uint32_t max_h, hipStream_t stream)
+                      uint32_t max_h, int cull, hipStream_t stream)
 {
     if (a.n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
     const uint32_t tiles_x = (max_w + 15u) / 16u, tiles_y = (max_h + 15u) / 16u;
@@ -144,7 +151,7 @@ hipError_t launch_sdf(const RenderArgs &a, const int16_t *pts, const uint32_t *s
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sdf_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a.jobs, pts, seg_p0,
                        a.glyph_seg_start, a.glyph_rec_count, a.recs, reinterpret_cast<uint8_t *>(a.out),
-                       a.out_stride, tiles_x, tiles_y, a.phase_center);
+                       a.out_stride, tiles_x, tiles_y, a.phase_center, cull);
     return hipGetLastError();
 }
 

@@ -60,3 +60,38 @@ class Winding:                  # Image.zig:85-130
 
     def as_2d(self) -> np.ndarray:
         return self.data.reshape(self.height, self.width)
+
+
+@dataclass
+class RGB:                      # Image.zig:132-170
+    width: int
+    height: int
+    data: np.ndarray            # (height*width, 3) u8
+
+    def getWidth(self) -> int:
+        return self.width
+
+    def getHeight(self) -> int:
+        return self.height
+
+    def getRGBLinear(self, index: int):
+        return tuple(int(v) for v in self.data[index])
+
+    def as_3d(self) -> np.ndarray:
+        return self.data.reshape(self.height, self.width, 3)
+
+
+@dataclass
+class GlyphDebug:               # Image.zig:173-241
+    """Image.GlyphDebug: the exact-integer winding lattice (1 px per font unit, 1-unit border) coloured by
+    setWindingLinear with the glyph's points marked; `render` runs on the device through fr_glyph_debug_render."""
+    rgb: RGB
+    winding_scale: int
+    overflow_color: int = 150
+    on_curve_color: tuple = (255, 255, 0)
+    off_curve_color: tuple = (0, 255, 255)
+
+    @staticmethod
+    def render(glyph, winding_scale: int, *, ctx=None) -> "GlyphDebug":       # Image.zig:220
+        from . import render_glyph as rg
+        return GlyphDebug(rg.glyph_debug_render(glyph, winding_scale, ctx=ctx), winding_scale)

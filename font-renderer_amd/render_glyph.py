@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib as L
 from .glyph import FontInformation, Glyph, GlyphSet
-from .image import Gray, Winding
+from .image import RGB, Gray, Winding
 
 
 def _flat(glyph: Glyph):
@@ -122,6 +122,12 @@ class Plan:
     @property
     def pixels(self) -> int:
         return int(self.ctx._lib.fr_plan_pixels(self._h))
+
+    def stats(self) -> dict:
+        """how the jobs are split between the two render kernels (decided per job)"""
+        a, b = C.c_uint32(), C.c_uint32()
+        L.check(self.ctx._lib.fr_plan_stats(self._h, C.byref(a), C.byref(b)))
+        return {"jobs_cov4": a.value, "jobs_general": b.value}
 
     def render(self, out_dev_ptr: int, out_stride: int, out_rows: int) -> None:
         """asynchronous on the context's stream; out_dev_ptr is a DEVICE address"""
@@ -257,3 +263,19 @@ def exact_coverage(glyph: Glyph, K: int, x0: int, y0: int, w_px: int, h_px: int,
     out = np.zeros((h_px, w_px), np.uint8)
     L.check(ctx._lib.fr_exact_coverage(ctx._h, L.ptr(pts), L.ptr(cstart), nc, K, x0, y0, w_px, h_px, n, L.ptr(out)))
     return out
+
+
+def glyph_debug_render(glyph: Glyph, winding_scale: int, *, ctx: Optional[Context] = None) -> RGB:
+    """Image.GlyphDebug.render (Image.zig:220-240) through fr_glyph_debug_render: the exact-integer lattice
+    coloured by setWindingLinear (:192-200) with the glyph's points marked (:202-218)"""
+    ctx = ctx or default_context()
+    pts, cs, nc = _flat(glyph)
+    box = glyph.box.as_array()
+    W, H = int(box[2]) - int(box[0]) + 3, int(box[3]) - int(box[1]) + 3
+    out = np.zeros((H * W, 3), np.uint8)
+    L.check(ctx._lib.fr_glyph_debug_render(ctx._h, L.ptr(pts), L.ptr(cs), nc, L.ptr(box), winding_scale, L.ptr(out)))
+    return RGB(W, H, out)
+
+
+def build_id() -> str:
+    return L.load_library().fr_build_id().decode()

@@ -3,11 +3,12 @@
 Glyphs are independent (/root/reference/src/tools/render_glyph.zig:24-31 reads only
 its own glyph), so rank r owns the contiguous glyph range [n*r/W, n*(r+1)/W) and
 renders it into its own atlas rows: NO collective on the render path.  The optional
-last step gathers the row bands onto every rank with one all_gather (RCCL over xGMI
-on GPUs; gloo in the CPU tests)."""
+last step gathers the row bands onto every rank with ONE all_gather_into_tensor into a
+preallocated atlas (RCCL over xGMI on GPUs; gloo in the CPU tests) — equal bands, the
+last one trimmed; no Python list of tensors, no concatenation."""
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -21,17 +22,49 @@ def shard_ranges(n_items: int, world: int) -> List[Tuple[int, int]]:
     return [shard_range(n_items, r, world) for r in range(world)]
 
 
-def gather_atlas(local_rows: torch.Tensor, n_glyphs: int, cell: int, cols: int, group=None) -> torch.Tensor:
-    """local_rows: this rank's (rows_r*cell, cols*cell) band, rows_r = ceil(count_r/cols).
-    Returns the concatenation of every rank's band (ranks may own different row counts:
-    bands are padded to the largest, gathered in ONE collective, then trimmed)."""
+def band_rows(n_glyphs: int, cell: int, cols: int, world: int) -> List[int]:
+    """pixel rows of every rank's atlas band: ceil(count_r / cols) cell rows"""
+    return [((b - a + cols - 1) // cols) * cell for a, b in shard_ranges(n_glyphs, world)]
+
+
+def gather_buffer(n_glyphs: int, cell: int, cols: int, world: int, device, dtype=torch.uint8) -> torch.Tensor:
+    """the preallocated destination of gather_atlas: `world` equal bands of the largest band's height"""
+    pad = max(band_rows(n_glyphs, cell, cols, world))
+    return torch.empty((world * pad, cols * cell), dtype=dtype, device=device)
+
+
+def gather_atlas(local_rows: torch.Tensor, n_glyphs: int, cell: int, cols: int, group=None,
+                 out: Optional[torch.Tensor] = None, compact: bool = True) -> torch.Tensor:
+    """local_rows: this rank's band — either exactly its own rows_r x (cols*cell), or already a view of the
+    padded band (pad x cols*cell).  One all_gather_into_tensor into `out` (gather_buffer(...); allocated here
+    when None).  Bands are equal-sized slots of the largest band's height; ranks whose band is shorter leave
+    the tail of their slot unspecified.  Returns the atlas: `out` itself when every band fills its slot (the
+    usual case: n_glyphs a multiple of world * cols), else — with compact=True — the bands moved up against
+    each other inside `out` (in place, rank by rank) and the view of the rows in use."""
     world = dist.get_world_size(group)
-    counts = [b - a for a, b in shard_ranges(n_glyphs, world)]
-    rows = [((c + cols - 1) // cols) * cell for c in counts]
+    rows = band_rows(n_glyphs, cell, cols, world)
     pad = max(rows)
-    buf = local_rows
-    if buf.shape[0] < pad:
-        buf = torch.cat([buf, buf.new_zeros((pad - buf.shape[0], buf.shape[1]))], 0)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf.contiguous(), group=group)
-    return torch.cat([o[:r] for o, r in zip(out, rows)], 0)
+    if out is None:
+        out = gather_buffer(n_glyphs, cell, cols, world, local_rows.device, local_rows.dtype)
+    assert out.shape == (world * pad, local_rows.shape[1]) and out.is_contiguous()
+    src = local_rows
+    if src.shape[0] != pad:                       # a short band: stage it in this rank's own slot of `out`
+        rank = dist.get_rank(group)
+        slot = out[rank * pad:(rank + 1) * pad]
+        slot[:src.shape[0]].copy_(src)
+        src = slot
+    if dist.get_backend(group) != "nccl":
+        src = src.clone()                         # (only RCCL documents the in-place form: input = own slot of the output)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    if not compact or all(r == pad for r in rows):
+        return out
+    dst = rows[0]
+    for r in range(1, world):                     # move band r up against band r - 1 (overlap-safe: row chunks, top down)
+        if dst != r * pad and rows[r]:
+            band = out[r * pad:r * pad + rows[r]]
+            if dst + rows[r] <= r * pad:
+                out[dst:dst + rows[r]].copy_(band)
+            else:
+                out[dst:dst + rows[r]].copy_(band.clone())
+        dst += rows[r]
+    return out[:dst]

@@ -92,6 +92,8 @@ typedef struct fr_plan fr_plan;
 /* ---- library / context -------------------------------------------------- */
 int fr_abi_version(void);
 const char *fr_last_error(void);
+/* a string that changes whenever a kernel of the hot path does (profiles/traffic.json is keyed by it) */
+const char *fr_build_id(void);
 
 /* device: HIP device ordinal.  hip_stream: a hipStream_t to launch on (e.g. the
  * caller's torch stream), or NULL to let the context create and own one.       */
@@ -100,7 +102,9 @@ void fr_ctx_destroy(fr_ctx *ctx);
 int fr_ctx_sync(fr_ctx *ctx);
 /* tuning / test knobs: "kmax" (crossings kept per sample row, in registers, before the
  * exact direct-sum fallback: rounded up to 8, 16 or 32; default 32), "strip_px" (column
- * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip) */
+ * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip),
+ * "cov4" (0: every job takes the general kernel), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
+ * every pixel — the culls are exact, this is how the tests show it), "min_wgs", "fuse_prepare", "lds_pad" */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 
 /* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------
@@ -129,9 +133,9 @@ int fr_glyphset_stats(const fr_glyphset *gs, uint64_t *n_segments, uint64_t *n_r
 int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint32_t n_jobs,
                    const fr_raster_params *params, fr_plan **out);
 void fr_plan_destroy(fr_plan *plan);
-/* Every render starts from the glyph POINTS (nothing derived is reused between renders): when
- * all glyphs of the set have <= 128 segments the render kernel builds each glyph's root records
- * itself, in LDS ("fused"); otherwise the precompute kernel is re-run first.
+/* Every render starts from the glyph POINTS (nothing derived is reused between renders): the render
+ * kernels build the root records of a glyph of <= 128 (general kernel) / <= 256 (cov4 kernel) segments
+ * themselves, in LDS ("fused", decided per job); the precompute kernel is re-run first for the larger glyphs only.
  * Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
  * out_rows rows of out_stride elements (u8, or i16 for FR_WINDING_I16); every job
  * must fit inside it (checked).  Pixels outside all jobs are not touched.           */
@@ -139,6 +143,10 @@ int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_r
 /* same, bracketed by HIP events on the launch stream; synchronous; *ms = kernel time */
 int fr_plan_render_timed(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows, float *ms);
 uint64_t fr_plan_pixels(const fr_plan *plan);   /* sum of w*h over the jobs */
+/* how the plan's jobs are split between the two render kernels (the decision is per job): cov4_kernel
+ * (16-sample coverage of cells that are whole 128- / 256-pixel strips and 16-row bands, <= 256 pixels tall,
+ * glyphs of <= 256 segments) and the general render_kernel (everything else)                          */
+int fr_plan_stats(const fr_plan *plan, uint32_t *n_jobs_cov4, uint32_t *n_jobs_general);
 
 /* One-shot: plan + render + copy back.  out_host: HOST buffer (caller-allocated,
  * e.g. Image.Gray.data / Image.Winding.data from the Zig allocator).  Synchronous.  */
@@ -172,6 +180,13 @@ int fr_winding_in_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *c
 int fr_winding_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                        uint32_t n_contours, const int16_t box[4], int16_t *out_host);
 
+/* Image.GlyphDebug.render (Image.zig:220-240): the lattice of fr_winding_lattice coloured by
+ * setWindingLinear (:192-200; overflow colour 150) with the glyph's on-curve / control points marked
+ * {255,255,0} / {0,255,255} by setGlyphPoints (:202-218, in the reference's order).  rgb_host receives
+ * (x_max-x_min+3) * (y_max-y_min+3) RGB triples, row-major — Image.RGB.data (Image.zig:132-170).        */
+int fr_glyph_debug_render(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
+                          uint32_t n_contours, const int16_t box[4], uint8_t winding_scale, uint8_t *rgb_host);
+
 /* ---- exact-integer sampling on a K-times refined lattice (BUILD-DEFINED) ----
  * GlyphInfo.init + windingInGlyph (render_glyph.zig:110-146, :160-300) applied, rule for rule, to
  * the glyph whose points are multiplied by K (1 <= K <= 8, so the 128-bit predicates cannot
@@ -188,6 +203,20 @@ int fr_exact_lattice(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *cont
 int fr_exact_coverage(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *contour_start,
                       uint32_t n_contours, uint32_t K, int32_t x0, int32_t y0, uint32_t w_px, uint32_t h_px,
                       uint32_t n, uint8_t *out_host /* [h_px][w_px] */);
+
+/* ---- atlas layout (host side; BUILD-DEFINED: the reference has no atlas) -------------------
+ * The fixed cell grid every atlas of this library uses: glyph i of `n_glyphs` (index first_glyph + i in
+ * the glyph set, box boxes[4 i ..]) gets a cell x cell window whose pixel (0,0) is the glyph's own
+ * renderGlyph origin — scale = f32(font_size) / f32(units_per_em), min_x = floor(x_min * scale),
+ * max_y = ceil(y_max * scale) in binary32 exactly as render_glyph.zig:13-17 — at column (i % cols),
+ * row (i / cols) of a cols-wide grid.  rows_per_page > 0 cuts the grid into pages of that many cell rows
+ * (a 2048^2 page of 128-pixel cells: cols = rows_per_page = 16): out_y restarts on every page and
+ * page_of_job[i] (if not NULL) names the page; *n_pages (if not NULL) receives the page count.
+ * units_per_em: n_upm = 1 (one font) or n_upm = n_glyphs (one value per glyph).                      */
+int fr_atlas_layout(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyph,
+                    const uint16_t *units_per_em, uint32_t n_upm, uint16_t font_size,
+                    uint32_t cell, uint32_t cols, uint32_t rows_per_page,
+                    fr_job *jobs_out, uint32_t *page_of_job, uint32_t *n_pages);
 
 /* ---- contour producer (host side): TrueType glyf/loca -> Glyph contour layout ------------
  * What font/Font.zig + font/ttf.zig + font/Glyph.zig do in the reference (Font.initTTF :31,

@@ -64,3 +64,49 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in txt and "fr_oracle" not in txt and "libfr_oracle" not in txt, f
+
+
+def test_atlas_layout_matches_the_reference_formula(ascii_set):
+    """fr_atlas_layout (host side of the C ABI): scale, floor / ceil in binary32 as render_glyph.zig:13-17,
+    cell grid, pages — against the same formula written with numpy float32"""
+    from font_renderer_amd.atlas import cell_jobs
+    gs = ascii_set.gs
+    n, cell, size, cols = 95, 128, 100, 16
+    jobs, pages, n_pages = cell_jobs(gs, cell, size, ascii_set.g_upm, cols, first_glyph=95, n_glyphs=n, page_rows=2, return_pages=True)
+    upm = ascii_set.g_upm[95:95 + n].astype(np.float32)
+    scale = np.float32(size) / upm
+    box = gs.boxes[95:95 + n].astype(np.float32)
+    idx = np.arange(n)
+    assert np.array_equal(jobs["glyph"], idx + 95)
+    assert np.array_equal(jobs["scale"], scale)
+    assert np.array_equal(jobs["min_x"], np.floor(box[:, 0] * scale).astype(np.int32))
+    assert np.array_equal(jobs["max_y"], np.ceil(box[:, 3] * scale).astype(np.int32))
+    assert (jobs["w"] == cell).all() and (jobs["h"] == cell).all()
+    assert np.array_equal(jobs["out_x"], (idx % cols) * cell)
+    assert np.array_equal(jobs["out_y"], ((idx % 32) // cols) * cell)       # two cell rows per page
+    assert np.array_equal(pages, idx // 32) and n_pages == 3
+    flat = cell_jobs(gs, 64, 50, 1000, 8, n_glyphs=20)                       # one units_per_em, no pages
+    assert np.array_equal(flat["out_y"], (np.arange(20) // 8) * 64) and flat["scale"][0] == np.float32(50) / np.float32(1000)
+    with pytest.raises(fr.FrError):
+        cell_jobs(gs, 0, 50, 1000, 8, n_glyphs=4)
+
+
+def test_qoi_writer_decodes_with_an_independent_decoder(oracle):
+    """fr_qoi_encode_rgb / _gray (qoi.zig:25-88) decoded by Pillow's QOI plugin — a decoder this build did not
+    write — and byte-identical to the oracle's restatement"""
+    import io
+    from PIL import Image as PILImage
+    from font_renderer_amd import qoi
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (37, 29, 3), dtype=np.uint8)
+    img[5:15] = img[5, 0]                       # runs longer than 62
+    img[20, :, :] = (np.arange(29) * 3)[:, None]
+    img[21:25] = img[21:25] // 64 * 64          # few colours: index hits
+    stream = qoi.saveRGB(img)
+    assert stream == oracle.qoi_encode(img)
+    dec = np.asarray(PILImage.open(io.BytesIO(stream)).convert("RGB"))
+    assert np.array_equal(dec, img)
+    gray = rng.integers(0, 256, (19, 33), dtype=np.uint8)
+    gray[4:9] = 200
+    dec = np.asarray(PILImage.open(io.BytesIO(qoi.saveRGB(gray))).convert("RGB"))
+    assert np.array_equal(dec, np.repeat(gray[:, :, None], 3, 2))

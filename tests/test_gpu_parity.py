@@ -469,6 +469,152 @@ def test_full_size_properties_config3(ctx):
     sp.close(); sd.close(); plan.close(); dgs.close()
 
 
+def test_full_size_properties_config4_shard(ctx, oracle):
+    """BASELINE configs[3] per-GPU share at FULL size (63 488 / 8 = 7 936 glyphs x 128^2, S = 32, 16 samples per
+    pixel): re-render idempotent, 8 sub-shards rendered one after another == the unsharded atlas, the general
+    kernel (ctx option cov4 = 0) gives the same bytes as cov4_kernel, and 6 cells against the oracle."""
+    import torch
+    from font_renderer_amd.shard import shard_ranges
+    G, cols, cell = 7936, 64, 128
+    gs = synth_glyphset(G, 32)
+    H, W = atlas_shape(G, cell, cols)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    jobs = cell_jobs(gs, cell, cell, 2048, cols)
+    out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    assert plan.pixels == G * cell * cell and plan.stats() == {"jobs_cov4": G, "jobs_general": 0}
+    plan.render(out.data_ptr(), W, H); ctx.sync()
+    first = out.clone()
+    plan.render(out.data_ptr(), W, H); ctx.sync()
+    assert torch.equal(out, first)
+    plan.close()
+    out2 = torch.zeros_like(out)
+    torch.cuda.synchronize()
+    for lo, hi in shard_ranges(G, 8):                                # 992 glyphs = 15.5 atlas rows: ragged bands
+        sub = gs.subset(lo, hi)
+        sd = fr.DeviceGlyphSet(ctx, sub)
+        sj = cell_jobs(sub, cell, cell, 2048, cols).copy()
+        sj["out_x"] = ((np.arange(lo, hi) % cols) * cell).astype(np.uint32)      # keep every glyph in its unsharded cell
+        sj["out_y"] = ((np.arange(lo, hi) // cols) * cell).astype(np.uint32)
+        sp = fr.Plan(sd, sj, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        sp.render(out2.data_ptr(), W, H); ctx.sync()
+        sp.close(); sd.close()
+    assert torch.equal(out2, first)
+    try:
+        ctx.set_option("cov4", 0)
+        gp = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        assert gp.stats()["jobs_cov4"] == 0
+        out2.zero_(); torch.cuda.synchronize()
+        gp.render(out2.data_ptr(), W, H); ctx.sync()
+        gp.close()
+    finally:
+        ctx.set_option("cov4", 1)
+    assert torch.equal(out2, first)
+    dgs.close()
+    host = first.cpu().numpy()
+    for gi in (0, 63, 64, 3000, 7000, G - 1):
+        g1 = synth_glyphset(1, 32, first_index=gi)
+        ref = np.zeros((cell, cell), np.uint8)
+        oracle.render_batch(g1, cell_jobs(g1, cell, cell, 2048, 1), O.COVERAGE_U8, ref, 4, True)
+        y, x = (gi // cols) * cell, (gi % cols) * cell
+        assert np.array_equal(host[y:y + cell, x:x + cell], ref), gi
+
+
+def test_sdf_config5_cells_and_exact_culls(ctx, oracle):
+    """BASELINE configs[4] shape: SDF at 512 x 512 per glyph (two 256-pixel strips per cell) on 3 synthetic S = 64
+    glyphs against the CPU twin; and the claim behind the kernel's two culls (a tile drops segments beyond the
+    encoding's reach, a pixel skips segments no nearer than its best so far): with the culls switched off (ctx
+    option sdf_cull = 0) the bytes are the same — on the 512^2 cells and on 1 500 small random cells."""
+    gs = synth_glyphset(3, 64, first_index=5151)
+    jobs = cell_jobs(gs, 512, 512, 2048, 3)
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_SDF_U8, (512, 1536), 1, True, threads=16)
+    assert np.array_equal(got, ref)
+    assert got.min() == 0 and got.max() == 255
+    try:
+        ctx.set_option("sdf_cull", 0)
+        dgs = fr.DeviceGlyphSet(ctx, gs)
+        plain = np.zeros_like(got)
+        rg.render_batch(dgs, jobs, fr.FR_SDF_U8, plain, 1, fr.FR_SAMPLE_CENTER)
+        dgs.close()
+    finally:
+        ctx.set_option("sdf_cull", 1)
+    assert np.array_equal(plain, got)
+    # many small cells at random scales and origins (cull decisions at every distance from the outline)
+    gs = synth_glyphset(30, 48, first_index=9300)
+    rng = np.random.default_rng(77)
+    rows = []
+    for k in range(1500):
+        gi = int(rng.integers(0, 30))
+        s = np.float32(rng.integers(16, 700)) / np.float32(2048)
+        rows.append((gi, int(rng.integers(-40, int(2048 * s))), int(rng.integers(0, int(2048 * s) + 40)), 32, 32, (k % 50) * 32, (k // 50) * 32, s))
+    jobs = rg.make_jobs(rows)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    a = np.zeros((30 * 32, 50 * 32), np.uint8)
+    b = np.zeros_like(a)
+    rg.render_batch(dgs, jobs, fr.FR_SDF_U8, a, 1, fr.FR_SAMPLE_CORNER)
+    try:
+        ctx.set_option("sdf_cull", 0)
+        rg.render_batch(dgs, jobs, fr.FR_SDF_U8, b, 1, fr.FR_SAMPLE_CORNER)
+    finally:
+        ctx.set_option("sdf_cull", 1)
+    dgs.close()
+    assert np.array_equal(a, b)
+    assert 0 < (a == 0).mean() < 1 and 0 < (a == 255).mean() < 1
+
+
+def test_glyph_debug_render_and_atlas_page_to_qoi(ctx, oracle, ascii_set):
+    """SURVEY §8 f-4 / f-2 in the product: Image.GlyphDebug.render (Image.zig:173-241) through
+    fr_glyph_debug_render == the oracle's restatement; a GPU-rendered 2048^2 atlas page (configs[1]: 95 ASCII
+    glyphs, 128-pixel cells, laid out by fr_atlas_layout) -> fr_qoi_encode_gray -> decoded by Pillow == the page,
+    and the stream == the oracle's encoder on the oracle's page."""
+    import io
+    from PIL import Image as PILImage
+    from font_renderer_amd import qoi
+    for font, ch, ws in (("STIX", "i", 50), ("DejaVu", "g", 200), ("STIX", "A", 255)):
+        g = ascii_set.glyph(ascii_set.find(font, ch))
+        dbg = fr.GlyphDebug.render(g, ws, ctx=ctx)
+        want = oracle.glyph_debug_render(g, ws)
+        assert (dbg.rgb.height, dbg.rgb.width) == want.shape[:2]
+        assert np.array_equal(dbg.rgb.as_3d(), want), (font, ch)
+    gs = ascii_set.gs
+    jobs, pages, n_pages = cell_jobs(gs, 128, 100, ascii_set.g_upm, 16, first_glyph=0, n_glyphs=95, page_rows=16, return_pages=True)
+    assert n_pages == 1 and (pages == 0).all()
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, (2048, 2048), 4, True)
+    got[got == 7] = 0; ref[ref == 7] = 0          # (cells past the 95th keep the canvas value of _batch_both)
+    assert np.array_equal(got, ref)
+    stream = qoi.saveRGB(got)
+    dec = np.asarray(PILImage.open(io.BytesIO(stream)).convert("RGB"))
+    assert np.array_equal(dec[:, :, 0], got) and np.array_equal(dec[:, :, 1], got) and np.array_equal(dec[:, :, 2], got)
+    assert stream == oracle.qoi_encode(np.repeat(ref[:, :, None], 3, 2))
+
+
+def test_two_contexts_two_streams_one_thread(ctx, oracle):
+    """the shape a single-threaded Zig host would give a multi-stream job: two fr_ctx (own streams) driven
+    alternately from one thread, renders in flight on both; each result equals the oracle"""
+    import torch
+    gs_a, gs_b = synth_glyphset(24, 64, first_index=70), stroke_glyphset(24, 96, first_index=71)
+    cell, cols = 128, 8
+    with fr.Context(0) as ca, fr.Context(0) as cb:
+        da, db = fr.DeviceGlyphSet(ca, gs_a), fr.DeviceGlyphSet(cb, gs_b)
+        ja, jb = cell_jobs(gs_a, cell, cell, 2048, cols), cell_jobs(gs_b, cell, cell, 2048, cols)
+        pa = fr.Plan(da, ja, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        pb = fr.Plan(db, jb, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        H, W = atlas_shape(24, cell, cols)
+        oa = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        ob = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):                         # interleaved launches, nothing waited for in between
+            pa.render(oa.data_ptr(), W, H)
+            pb.render(ob.data_ptr(), W, H)
+        ca.sync(); cb.sync()
+        pa.close(); pb.close(); da.close(); db.close()
+    for gsx, jx, ox in ((gs_a, ja, oa), (gs_b, jb, ob)):
+        ref = np.zeros((H, W), np.uint8)
+        oracle.render_batch(gsx, jx, O.COVERAGE_U8, ref, 4, True, 16)
+        assert np.array_equal(ox.cpu().numpy(), ref)
+
+
 def test_oracle_spot_check_inside_full_size_workload(ctx, oracle):
     """4 cells of the C3 workload (first, two middle, last glyph index) against the oracle."""
     G = 20992

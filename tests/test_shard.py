@@ -17,21 +17,29 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, initfile, outdir, n_glyphs, cell, cols):
+def _worker(rank, world, initfile, outdir, n_glyphs, cell, cols, use_gpu=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-    import oracle_lib
     from font_renderer_amd.atlas import atlas_shape, cell_jobs
     from font_renderer_amd.shard import gather_atlas, shard_range
     from font_renderer_amd.synth import synth_glyphset
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
     try:
-        orc = oracle_lib.Oracle()
         gs = synth_glyphset(n_glyphs, 24)
         lo, hi = shard_range(n_glyphs, rank, world)
         sub = gs.subset(lo, hi)                                  # only this rank's points travel to "its GPU"
         jobs = cell_jobs(sub, cell, cell, 2048, cols)
         band = np.zeros(atlas_shape(hi - lo, cell, cols), np.uint8)
-        orc.render_batch(sub, jobs, oracle_lib.COVERAGE_U8, band, 2, True)
+        if use_gpu:
+            # both ranks drive the LIBRARY (each its own fr_ctx) on the one GPU of the box; the gather stays gloo
+            import font_renderer_amd as fr
+            from font_renderer_amd import render_glyph as rg
+            with fr.Context(0) as ctx:
+                dgs = fr.DeviceGlyphSet(ctx, sub)
+                rg.render_batch(dgs, jobs, fr.FR_COVERAGE_U8, band, 2, fr.FR_SAMPLE_CENTER)
+                dgs.close()
+        else:
+            import oracle_lib
+            oracle_lib.Oracle().render_batch(sub, jobs, oracle_lib.COVERAGE_U8, band, 2, True)
         full = gather_atlas(torch.from_numpy(band), n_glyphs, cell, cols)
         np.save(os.path.join(outdir, f"rank{rank}.npy"), full.numpy())
     finally:
@@ -47,14 +55,14 @@ def test_shard_ranges_cover_everything():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
-def test_two_rank_gloo_gather_equals_unsharded(oracle):
+def _check_two_rank_gather(oracle, n_glyphs, use_gpu):
     from font_renderer_amd.atlas import atlas_shape, cell_jobs
     from font_renderer_amd.shard import shard_ranges
     from font_renderer_amd.synth import synth_glyphset
-    n_glyphs, cell, cols, world = 22, 24, 4, 2          # 11 glyphs per rank: ragged last rows on both
+    cell, cols, world = 24, 4, 2
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
-        mp.spawn(_worker, args=(world, initfile, d, n_glyphs, cell, cols), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, initfile, d, n_glyphs, cell, cols, use_gpu), nprocs=world, join=True)
         got = [np.load(os.path.join(d, f"rank{r}.npy")) for r in range(world)]
     assert np.array_equal(got[0], got[1])
     # expected: each rank's band is a cols-wide atlas of its own glyphs, bands stacked in rank order
@@ -75,3 +83,17 @@ def test_two_rank_gloo_gather_equals_unsharded(oracle):
     r1_row0 = atlas_shape(lo1, cell, cols)[0]
     gy, gx = (lo1 // cols) * cell, (lo1 % cols) * cell
     assert np.array_equal(whole[gy:gy + cell, gx:gx + cell], got[0][r1_row0:r1_row0 + cell, :cell])
+
+
+@pytest.mark.parametrize("n_glyphs", [22, 17])
+def test_two_rank_gloo_gather_equals_unsharded(oracle, n_glyphs):
+    """22 glyphs: 11 per rank, equal bands with ragged last rows (the gathered buffer is the atlas as it is);
+    17 glyphs: 8 + 9 -> bands of 2 and 3 cell rows (the short band's slot is trimmed, in place)"""
+    _check_two_rank_gather(oracle, n_glyphs, False)
+
+
+@pytest.mark.gpu
+def test_two_ranks_render_with_the_library_on_one_gpu(oracle):
+    """the N > 1 path with the product in it: two gloo ranks, each with its own fr_ctx on the box's one GPU,
+    render their shards through libfr_raster and gather; equal to the oracle's unsharded bytes"""
+    _check_two_rank_gather(oracle, 22, True)
