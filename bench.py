@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — whole-job throughput of the hot path (AA glyph coverage) on N MI355X.
 
-One "step" = one pass of the hot path over one batch: the per-segment precompute kernel
-(root records) + the render kernel, from parsed quadratic contours resident in HBM to the
-anti-aliased u8 coverage atlas resident in HBM.  Synthetic outlines; each
-rank owns its own contiguous glyph range and atlas band — no collective on the data path
-(weak scaling).
+One "step" = one pass of the hot path over one batch: everything from parsed quadratic contours
+resident in HBM to the anti-aliased u8 coverage atlas resident in HBM (root records rebuilt inside
+the render kernels every step; the stand-alone precompute kernel runs first for glyphs too large
+for that).  Synthetic outlines unless the workload names a font; each rank owns a
+contiguous glyph range and its own atlas band — no collective on the data path.
+
+N > 1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU, RCCL); bench.py never spawns ranks itself.  Weak scaling by default (the workload's
+glyph count PER GPU); `--total-glyphs T` fixes the job size instead (strong scaling: configs[3] /
+configs[4] are fixed-size jobs).  With N > 1 the optional assembly of the atlas bands is timed too (one
+all_gather_into_tensor, reported separately: gather_ms / gather_GBps — never part of `value`; --no-gather skips it).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md §7 for every field's derivation."""
 import argparse
@@ -20,12 +26,14 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DEJAVU = "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"
 
 WORKLOADS = {
-    # BASELINE.json configs[2]: the largest single-GPU configuration (~21k CJK-like glyphs)
+    # BASELINE.json configs[2]: the largest single-GPU configuration (~21k CJK-like glyphs) — the headline
     "c3_cjk21k_256px_s128_16spp": dict(glyphs=20992, cell=256, segs=128, n=4, cols=64),
     # BASELINE.json configs[1]: 95 glyphs, 128x128 cells, one 2048^2 atlas
     "c2_ascii95_128px_s32_16spp": dict(glyphs=95, cell=128, segs=32, n=4, cols=16),
+    "c2_ascii95_real_128px_16spp": dict(glyphs=95, cell=128, segs=0, n=4, cols=16, gen="ascii"),
     # BASELINE.json configs[3] per-GPU share (BMP/8 = 7936 glyphs, 128^2, 16 samples)
     "c4_bmp_shard_128px_s32_16spp": dict(glyphs=7936, cell=128, segs=32, n=4, cols=64),
     # BASELINE.json configs[4] per-GPU share (4 096 glyphs / 8 = 512, 512^2 cells): build-defined SDF, 1 sample
@@ -33,17 +41,43 @@ WORKLOADS = {
     # SURVEY §8(d) segment list {16, 32, 64, 128, 256}: the C3 shape at the other segment counts
     "c3_cjk21k_256px_s256_16spp": dict(glyphs=20992, cell=256, segs=256, n=4, cols=64),
     "c3_cjk21k_256px_s64_16spp": dict(glyphs=20992, cell=256, segs=64, n=4, cols=64),
+    "c3_cjk21k_256px_s32_16spp": dict(glyphs=20992, cell=256, segs=32, n=4, cols=64),
     "c3_cjk21k_256px_s16_16spp": dict(glyphs=20992, cell=256, segs=16, n=4, cols=64),
     # stroke-dense outlines: 8-16 thin strokes per glyph, 10-30 crossings per ray (synth.stroke_glyph)
     "c3_strokes21k_256px_s128_16spp": dict(glyphs=20992, cell=256, segs=128, n=4, cols=64, gen="stroke"),
-    # a real font through the C-side contour producer (fr_font_*): every glyph of DejaVuSerif-Italic the reference
-    # could load (~3 000, up to 347 segments), 4 sizes each -> 256^2 cells
-    "real_dejavuserif_italic_whole_font_256px_16spp": dict(glyphs=0, cell=256, segs=0, n=4, cols=64, gen="font",
-                                                           font="/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"),
-    # the reference's own products (one sample per pixel, the pixel corner): renderGlyph's value map and Image.Winding
+    # a real font through the C-side contour producer (fr_font_*): every glyph of DejaVuSerif-Italic the
+    # reference could load (~3 000 glyphs, up to 347 segments), at 6 font sizes -> 256^2 cells
+    "real_dejavuserif_italic_whole_font_256px_16spp": dict(glyphs=0, cell=256, segs=0, n=4, cols=64, gen="font", font=DEJAVU),
+    # the reference's own products (one sample per pixel, the pixel corner): renderGlyph's value map, Image.Winding
     "c3_cjk21k_256px_s128_gray_debug": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="gray_debug"),
     "c3_cjk21k_256px_s128_winding_i16": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="winding_i16"),
 }
+
+
+def build_inputs(wl, rank, lo, hi):
+    """-> (GlyphSet, jobs, (H, W)) for this rank's glyph range [lo, hi) of the workload"""
+    from font_renderer_amd.atlas import atlas_shape, cell_jobs
+    from font_renderer_amd.synth import stroke_glyphset, synth_glyphset
+    cell, cols, gen = wl["cell"], wl["cols"], wl.get("gen", "synth")
+    if gen == "font":
+        import font_renderer_amd as fr
+        font = fr.Font.initTTF(wl["font"])
+        gs, kept = font.glyphset()
+        upm = font.information.units_per_em
+        sizes = [int(cell * f) for f in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5)]
+        jobs = np.concatenate([cell_jobs(gs, cell, s, upm, cols) for s in sizes])
+        k = np.arange(len(jobs))
+        jobs["out_x"] = (k % cols) * cell
+        jobs["out_y"] = (k // cols) * cell
+        return gs, jobs, atlas_shape(len(jobs), cell, cols)
+    if gen == "ascii":
+        import fixtures
+        asc = fixtures.load_ascii()
+        jobs = cell_jobs(asc.gs, cell, 100, asc.g_upm, cols, first_glyph=0, n_glyphs=95)
+        return asc.gs, jobs, atlas_shape(95, cell, cols)
+    make = stroke_glyphset if gen == "stroke" else synth_glyphset
+    gs = make(hi - lo, wl["segs"], first_index=lo)
+    return gs, cell_jobs(gs, cell, cell, 2048, cols), atlas_shape(hi - lo, cell, cols)
 
 
 def main():
@@ -52,24 +86,28 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3_cjk21k_256px_s128_16spp", choices=sorted(WORKLOADS))
-    ap.add_argument("--glyphs", type=int, default=0, help="override glyph count (smoke runs)")
+    ap.add_argument("--glyphs", type=int, default=0, help="override the per-GPU glyph count (smoke runs)")
+    ap.add_argument("--total-glyphs", type=int, default=0, help="strong scaling: the whole job's glyph count, sharded over the ranks")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed all-gather of the atlas bands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kmax", type=int, default=0, help="crossings per sample row kept in registers (8/16/32)")
     ap.add_argument("--n", type=int, default=0, help="override samples per axis (experiments)")
     ap.add_argument("--segs", type=int, default=0, help="override segments per glyph (experiments)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (experiments)")
-    ap.add_argument("--no-prep-in-step", action="store_true", help="time the render kernel alone per step")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: bench.py runs ONE rank per process; launch N > 1 as "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {args.gpus} ...`")
+
+    import torch
+    import torch.distributed as dist
+
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU: the library has no CPU path")
@@ -86,8 +124,7 @@ def main():
             dist.init_process_group(backend)
 
     import font_renderer_amd as fr
-    from font_renderer_amd.atlas import atlas_shape, cell_jobs
-    from font_renderer_amd.synth import synth_glyphset
+    from font_renderer_amd.shard import gather_atlas, gather_buffer, shard_range
 
     wl = dict(WORKLOADS[args.workload])
     if args.glyphs:
@@ -96,14 +133,24 @@ def main():
         wl["n"] = args.n
     if args.segs:
         wl["segs"] = args.segs
-    G, cell, S, n, cols = wl["glyphs"], wl["cell"], wl["segs"], wl["n"], wl["cols"]
-    sdf = wl.get("mode") == "sdf"
+    cell, S, n, cols = wl["cell"], wl["segs"], wl["n"], wl["cols"]
+    mode_name = wl.get("mode", "coverage")
+    mode = {"coverage": fr.FR_COVERAGE_U8, "sdf": fr.FR_SDF_U8, "gray_debug": fr.FR_GRAY_DEBUG, "winding_i16": fr.FR_WINDING_I16}[mode_name]
+    bpp = 2 if mode == fr.FR_WINDING_I16 else 1
+    phase = fr.FR_SAMPLE_CORNER if mode_name in ("gray_debug", "winding_i16") else fr.FR_SAMPLE_CENTER
+    strong = args.total_glyphs > 0
+    if strong:
+        lo, hi = shard_range(args.total_glyphs, rank, world)
+        total_glyphs = args.total_glyphs
+    else:
+        lo, hi = rank * wl["glyphs"], (rank + 1) * wl["glyphs"]
+        total_glyphs = wl["glyphs"] * world
 
-    # ---- inputs: this rank's glyph range (weak scaling: G glyphs per GPU)
+    # ---- inputs: this rank's glyph range
     t_gen = time.time()
-    gs = synth_glyphset(G, S, first_index=rank * G)
+    gs, jobs, (H, W) = build_inputs(wl, rank, lo, hi)
     t_gen = time.time() - t_gen
-    H, W = atlas_shape(G, cell, cols)
+    G = len(jobs)
     stream = torch.cuda.Stream()
     ctx = fr.Context(local, stream.cuda_stream)
     if args.kmax:
@@ -111,17 +158,26 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    with torch.cuda.stream(stream):
-        out = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    # the atlas band lives inside the gather destination when the gather is timed (no staging copy)
+    gbuf = None
+    if world > 1 and not args.no_gather and backend == "nccl" and wl.get("gen", "synth") in ("synth", "stroke"):
+        with torch.cuda.stream(stream):
+            gbuf = gather_buffer(total_glyphs, cell, cols, world, "cuda", torch.int16 if bpp == 2 else torch.uint8)
+            pad = gbuf.shape[0] // world
+            out = gbuf[rank * pad:rank * pad + H]
+            out.zero_()
+    else:
+        with torch.cuda.stream(stream):
+            out = torch.zeros((H, W), dtype=torch.int16 if bpp == 2 else torch.uint8, device="cuda")
     dgs = fr.DeviceGlyphSet(ctx, gs)                       # points -> HBM (+ first precompute)
-    jobs = cell_jobs(gs, cell, cell, 2048, cols)
-    plan = fr.Plan(dgs, jobs, fr.FR_SDF_U8 if sdf else fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER)
+    plan = fr.Plan(dgs, jobs, mode, n, phase)
     pixels = plan.pixels
     stats = dgs.stats()
+    pstats = plan.stats()
 
     def step():
         # one render = everything from the glyph points to the atlas (the root records are rebuilt
-        # inside the render kernel, or by the precompute kernel the library launches with it)
+        # inside the render kernels, or by the precompute kernel the library launches with them)
         plan.render(out.data_ptr(), W, H)
 
     def barrier():
@@ -140,61 +196,119 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tot_pixels = pixels
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        p = torch.tensor([pixels], dtype=torch.int64, device=dev)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        tot_pixels = int(p.item())
     ms_per_step = dt / args.steps * 1e3
-    value = pixels * world / (dt / args.steps) / 1e6        # Mpixel/s, whole job
+    value = tot_pixels / (dt / args.steps) / 1e6            # Mpixel/s, whole job
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel alone
+    # ---- optional assembly of the atlas bands, timed on its own ("gather reported separately")
+    gather = None
+    if gbuf is not None:
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                gather_atlas(gbuf[rank * pad:(rank + 1) * pad], total_glyphs, cell, cols, out=gbuf, compact=False)
+            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            tg = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                gather_atlas(gbuf[rank * pad:(rank + 1) * pad], total_glyphs, cell, cols, out=gbuf, compact=False)
+            torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg) / reps
+        if world > 1:
+            t = torch.tensor([tg], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tg = float(t.item())
+        gbytes = gbuf.numel() * gbuf.element_size()
+        gather = {"gather_ms": round(tg * 1e3, 4), "gather_GBps": round(gbytes / tg / 1e9, 2), "gathered_bytes": gbytes,
+                  "collective": f"all_gather_into_tensor ({backend}), every rank receives the whole atlas"}
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, the render alone
     kms = sorted(plan.render_timed(out.data_ptr(), W, H) for _ in range(max(5, min(args.steps, 20))))
     k_ms = float(np.mean(kms))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(stream):
-        ev0.record(stream)
-        for _ in range(5):
-            dgs.prepare()
-        ev1.record(stream)
-    torch.cuda.synchronize()
-    prep_ms = ev0.elapsed_time(ev1) / 5
-    achieved = pixels * 1.0 / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel)
-    traffic = None
+    achieved = pixels * bpp / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel; 2 for int16 windings)
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not args.glyphs and not strong:
         try:
-            traffic = json.load(open(tpath)).get(args.workload if not args.glyphs else "", {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get(args.workload, {})
+            if ent.get("build_id") == fr.build_id():          # counters of THIS kernel build only
+                traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "fr::render_kernel<COVERAGE_U8,1> + fr::sdf_kernel" if sdf else f"fr::render_kernel<COVERAGE_U8,{n}>",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": pixels, "kernel_ms": round(k_ms, 4),
-                "prepare_kernel_ms": round(prep_ms, 4)}
+    if mode == fr.FR_SDF_U8:
+        kname = "fr::render_kernel<COVERAGE_U8,1> + fr::sdf_kernel"
+    elif pstats["jobs_general"] == 0:
+        kname = f"fr::cov4_kernel<{4 if wl['cell'] % 256 == 0 else 3},32>"
+    elif pstats["jobs_cov4"] == 0:
+        kname = f"fr::render_kernel<{mode_name},{n}>"
+    else:
+        kname = f"fr::cov4_kernel ({pstats['jobs_cov4']} jobs) + fr::render_kernel ({pstats['jobs_general']} jobs)"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": pixels * bpp, "kernel_ms": round(k_ms, 4), "build_id": fr.build_id()}
+
+    # ---- configs[0]: the reference's own call shape — one glyph, one image (STIX 'A' at 64 -> 47 x 45), latency per call
+    c1 = None
+    if rank == 0 and world == 1:
+        try:
+            import ctypes as C
+            import fixtures
+            from font_renderer_amd import _lib as L
+            asc = fixtures.load_ascii()
+            i = asc.find("STIX", "A")
+            g, info = asc.glyph(i), fr.FontInformation(int(asc.g_upm[i]))
+            im = fr.renderGlyph(g, info, 64, ctx=ctx)                  # (also sizes the context's scratch)
+            gs1 = fr.GlyphSet([g])
+            pts, cs, box = gs1.points_xy, gs1.contour_start, g.box.as_array()
+            buf = np.zeros(im.width * im.height, np.uint8)
+            lib = L.load_library()
+            call = lambda: lib.fr_render_glyph(ctx._h, L.ptr(pts), L.ptr(cs), len(cs) - 1, L.ptr(box), info.units_per_em, 64, fr.FR_GRAY_DEBUG, L.ptr(buf))
+            for _ in range(50):
+                call()
+            tc = time.perf_counter()
+            for _ in range(500):
+                rc1 = call()
+            us = (time.perf_counter() - tc) / 500 * 1e6
+            assert rc1 == 0 and np.array_equal(buf, im.data)
+            c1 = {"config": "configs[0]: STIX 'A', font_size 64 -> 47x45 gray; one fr_render_glyph call (upload, render, download, sync)",
+                  "us_per_call": round(us, 1), "size": [im.width, im.height]}
+        except Exception as e:                               # fixtures are test data: absent -> no C1 line
+            c1 = {"error": str(e)}
 
     # ---- CPU baseline: the oracle (restated reference algorithm), rank 0, N = 1 only
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
+        from font_renderer_amd.atlas import atlas_shape
         orc = oracle_lib.Oracle()
         threads = min(len(os.sched_getaffinity(0)), 16)   # the GPU box grants 16 cores per GPU
+        omode = {"coverage": oracle_lib.COVERAGE_U8, "sdf": oracle_lib.SDF_U8, "gray_debug": oracle_lib.GRAY_DEBUG,
+                 "winding_i16": oracle_lib.WINDING_I16}[mode_name]
+        odt = np.int16 if bpp == 2 else np.uint8
+        center = phase == fr.FR_SAMPLE_CENTER
         probe = min(2, G)
-        buf = np.zeros(atlas_shape(probe, cell, cols), np.uint8)
+        buf = np.zeros(atlas_shape(probe, cell, cols), odt)
         t = time.perf_counter()
-        omode = oracle_lib.SDF_U8 if sdf else oracle_lib.COVERAGE_U8
-        orc.render_batch(gs, jobs[:probe], omode, buf, n, True, 1)
+        orc.render_batch(gs, jobs[:probe], omode, buf, n, center, 1)
         per_glyph = (time.perf_counter() - t) / probe
         ng = int(max(threads, min(G, args.cpu_seconds * threads / max(per_glyph, 1e-9))))
         unit = max(threads, cols)                      # whole atlas rows, so the sample can be compared with the GPU's bytes
         ng = min(G, (ng // unit) * unit if ng >= unit else ng)
-        buf = np.zeros(atlas_shape(ng, cell, cols), np.uint8)
+        buf = np.zeros(atlas_shape(ng, cell, cols), odt)
         t = time.perf_counter()
-        orc.render_batch(gs, jobs[:ng], omode, buf, n, True, threads)
+        orc.render_batch(gs, jobs[:ng], omode, buf, n, center, threads)
         ct = time.perf_counter() - t
         with torch.cuda.stream(stream):
             same = bool(np.array_equal(out[:buf.shape[0]].cpu().numpy(), buf)) if (ng % cols == 0 or ng <= cols) else None
         cpu = {"value": round(ng * cell * cell / ct / 1e6, 4), "unit": "Mpixel/s", "cores": threads, "kind": "port",
-               "sample": f"first {ng} glyphs of the same workload ({cell}x{cell}, {n * n} samples/pixel), "
+               "sample": f"first {ng} cells of the same workload ({cell}x{cell}, {n * n} samples/pixel), "
                          f"{ct:.1f} s wall on {threads} threads, oracle/fr_oracle.c (C restatement of "
                          f"render_glyph.zig, not the Zig binary)",
                "single_thread_value": round(cell * cell / per_glyph / 1e6, 4), "matches_gpu_bytes": same}
@@ -203,13 +317,15 @@ def main():
         line = {
             "metric": "Mpixel/s AA glyph coverage", "value": round(value, 1), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "glyphs_per_gpu": G, "cell": f"{cell}x{cell}", "segments_per_glyph": S,
-                       "samples_per_pixel": n * n, "mode": "sdf_u8" if sdf else "coverage_u8", "pixels_per_step_per_gpu": pixels,
-                       "root_records": stats["records"], "step": "points -> atlas (records rebuilt every render)",
-                       "parallelism": f"glyph-sharded x{world}, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if wl.get("gen", "synth") in ("synth", "stroke") else "real font outlines (matplotlib's DejaVuSerif-Italic / the committed ASCII fixture), random-free",
+            "config": {"workload": args.workload, "cells_per_gpu": G, "glyphs_in_set": len(gs), "cell": f"{cell}x{cell}",
+                       "segments_per_glyph": S if S else "as in the font", "total_segments_in_set": stats["segments"],
+                       "samples_per_pixel": n * n, "mode": mode_name if mode_name != "coverage" else "coverage_u8",
+                       "pixels_per_step_per_gpu": pixels, "pixels_per_step_whole_job": tot_pixels,
+                       "kernel_split": pstats, "step": "points -> atlas (records rebuilt every render)",
+                       "parallelism": f"glyph-sharded x{world}, no collective on the data path"},
+            "roofline": roofline, "cpu_baseline": cpu, "c1_single_glyph": c1, "gather": gather,
             "gpixel_per_s": round(value / 1e3, 2), "input_gen_s": round(t_gen, 2),
         }
         print(json.dumps(line), flush=True)

@@ -20,7 +20,7 @@ void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const u
                     uint32_t *, hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 uint32_t render_wg_waves();
-hipError_t launch_cov4(const RenderArgs &, hipStream_t);
+hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, hipStream_t);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, int cull, hipStream_t);
@@ -80,7 +80,8 @@ struct fr_ctx {
     // buffer, grown on demand and reused across calls
     unsigned char *arena = nullptr;
     size_t arena_cap = 0;
-    std::vector<unsigned char> stage;
+    unsigned char *stage = nullptr;     // pinned host memory: [upload block | image coming back]
+    size_t stage_cap = 0;
 };
 
 struct fr_glyphset {
@@ -104,7 +105,8 @@ struct fr_plan {
     uint32_t n_jobs = 0;
     // jobs cov4_kernel takes (fr_cov4.hip: 16-sample coverage, uniform cells, <= 256 root records): the first n_fast
     // entries of d_jobs / d_job_seg; the general kernel renders the other n_jobs - n_fast
-    uint32_t n_fast = 0;
+    uint32_t n_fast = 0;               // (of which the first n_fast256 need <= 256 record slots, the rest <= 512)
+    uint32_t n_fast256 = 0;
     uint32_t fast_bands = 0, fast_strips = 0, gen_bands = 0, gen_strips = 0;
     bool gen_uniform = false;
     fr_raster_params params{};
@@ -153,6 +155,7 @@ void fr_ctx_destroy(fr_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -415,14 +418,19 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     uint32_t n_fast = 0;
     {
         const bool mode_ok = ctx->cov4 && params->mode == FR_COVERAGE_U8 && n == 4u && (sw == 128u || sw == 256u);
-        std::vector<uint32_t> slow;
+        std::vector<uint32_t> mid, slow;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             const fr_job &jb = jobs[j];
             const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
             const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= 256u &&
-                              nsg <= fr::cov4_max_segments() && gs->h_root_bound[jb.glyph] <= 256u;
-            if (fast) order[n_fast++] = j; else slow.push_back(j);
+                              nsg <= fr::cov4_max_segments();
+            if (fast && gs->h_root_bound[jb.glyph] <= 256u) order[n_fast++] = j;
+            else if (fast) mid.push_back(j);           // (<= 256 segments: <= 512 candidate roots)
+            else slow.push_back(j);
         }
+        p->n_fast256 = n_fast;
+        std::copy(mid.begin(), mid.end(), order.begin() + n_fast);
+        n_fast += (uint32_t)mid.size();
         std::copy(slow.begin(), slow.end(), order.begin() + n_fast);
     }
     p->n_fast = n_fast;
@@ -537,12 +545,15 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     else if (n_gen && plan->n_large)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->d_large, plan->n_large,
                            plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
-    if (n_fast) {
-        a.jobs = plan->d_jobs;
-        a.job_seg = plan->d_job_seg;
-        a.n_jobs = n_fast; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
-        split_bands(fr::cov4_wg_waves(), n_fast, plan->fast_bands, plan->fast_strips);
-        HIP_TRY(fr::launch_cov4(a, plan->ctx->stream));
+    for (int part = 0; part < 2; ++part) {
+        // cov4_kernel: the jobs that fit 256 record slots (four workgroups per CU), then those that need 512 (three)
+        const uint32_t first = part ? plan->n_fast256 : 0u, cnt = part ? n_fast - plan->n_fast256 : plan->n_fast256;
+        if (!cnt) continue;
+        a.jobs = plan->d_jobs + first;
+        a.job_seg = plan->d_job_seg + 2u * (size_t)first;
+        a.n_jobs = cnt; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
+        split_bands(fr::cov4_wg_waves(), cnt, plan->fast_bands, plan->fast_strips);
+        HIP_TRY(fr::launch_cov4(a, part ? 512u : 256u, plan->ctx->stream));
     }
     if (n_gen) {
         a.jobs = plan->d_jobs + n_fast;
@@ -675,8 +686,16 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
         HIP_TRY(hipMalloc(&ctx->arena, cap));
         ctx->arena_cap = cap;
     }
-    ctx->stage.assign(up, 0);
-    unsigned char *st = ctx->stage.data();
+    const size_t img_bytes = (size_t)w * h * esz;
+    if (up + img_bytes > ctx->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
+        const size_t cap = std::max<size_t>((up + img_bytes) * 2, 1u << 16);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cap, hipHostMallocDefault));
+        ctx->stage_cap = cap;
+    }
+    unsigned char *st = ctx->stage;
+    memset(st, 0, up);
     if (np) memcpy(st + o_pts, points_xy, np * 4);
     if (ns) memcpy(st + o_p0, seg_p0.data(), (size_t)ns * 4);
     for (uint32_t sgi = 0; sgi < ns; ++sgi) memcpy(st + o_spts + 12u * (size_t)sgi, points_xy + 2u * (size_t)seg_p0[sgi], 12);
@@ -709,8 +728,9 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
     }
     if (lrc == FR_OK) lrc = plan_launch(&pl, A0 + o_out, w, h);
     hipError_t e = hipSuccess;
-    if (lrc == FR_OK) e = hipMemcpyAsync(out_host, A0 + o_out, (size_t)w * h * esz, hipMemcpyDeviceToHost, ctx->stream);
+    if (lrc == FR_OK) e = hipMemcpyAsync(st + up, A0 + o_out, img_bytes, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (lrc == FR_OK && e == hipSuccess && e2 == hipSuccess) memcpy(out_host, st + up, img_bytes);
     gs.d_pts = gs.d_seg_pts = nullptr; gs.d_seg_p0 = gs.d_glyph_seg_start = gs.d_rec_count = nullptr; gs.d_recs = nullptr;
     pl.d_jobs = nullptr; pl.d_job_seg = nullptr; pl.d_large = nullptr;
     if (lrc) return lrc;

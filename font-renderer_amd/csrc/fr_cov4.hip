@@ -161,11 +161,12 @@ __device__ __forceinline__ void c4_packed_sort(uint32_t (&d)[16])
 }
 
 // LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
-template <int WLOG>
+template <int WLOG, int RPL>
 struct C4Lds {
     static constexpr uint32_t NCOL = (16u << WLOG) * 4u;                    // sample columns of a strip
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;         // padded cx table
-    static constexpr uint32_t REC = 256u * (uint32_t)sizeof(Rec40);
+    static constexpr uint32_t RCAP = 64u * RPL;                             // root records a workgroup keeps
+    static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
     static constexpr uint32_t EROW = (16u << WLOG) + 16u;                   // bytes per pixel row of E (one 16-B pad)
     static constexpr uint32_t E = 16u * EROW;
     // walk buffers: lists [64][LSTRIDE] u16 | markers [PCAP] u16 | cy [64] f32 | cnt [64] u32 | roff [256] i16
@@ -174,7 +175,7 @@ struct C4Lds {
     static constexpr uint32_t OFF_CY = OFF_PAIRS + C4_PCAP * 2u;
     static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
     static constexpr uint32_t OFF_ROFF = OFF_CNT + 256u;
-    static constexpr uint32_t WALK = OFF_ROFF + 512u;
+    static constexpr uint32_t WALK = OFF_ROFF + RCAP * 2u;
     static constexpr uint32_t WAVE = (WALK > E ? WALK : E);
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
@@ -183,12 +184,14 @@ struct C4Lds {
 
 // One workgroup (8 waves) = one cell (or one group of its wave bands, or one 256-px strip of it).
 // WLOG: strip width 16 << WLOG pixels (3: 128, 4: 256).  CAP: crossings a sample row keeps (8 / 16 / 32);
-// fuller rows take the direct sum over the glyph's stand-alone records, as in the general kernel.
-template <int WLOG, int CAP>
+// fuller rows take the direct sum over the glyph's records.  RPL: root records per lane, 4 or 8 — a workgroup
+// keeps up to 64 RPL records in LDS (256: four workgroups per CU; 512: three).
+template <int WLOG, int CAP, int RPL>
 __global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
 void cov4_kernel(const RenderArgs A)
 {
-    using L = C4Lds<WLOG>;
+    using L = C4Lds<WLOG, RPL>;
+    constexpr uint32_t RCAP = L::RCAP;
     constexpr uint32_t NW = C4_WAVES;
     constexpr uint32_t SW = 16u << WLOG;            // strip width, pixels
     constexpr uint32_t NCOL = SW * 4u;              // sample columns
@@ -266,10 +269,10 @@ void cov4_kernel(const RenderArgs A)
         for (uint32_t it = 0; it < CPT; ++it)
             if ((lm[it] >> lane) & 1ull) {
                 const uint32_t pos = my_base[it] + (uint32_t)__popcll(lm[it] & ((1ull << lane) - 1ull));
-                if (pos < 256u) s_rec[pos] = mine[it];                      // (the plan only sends glyphs with <= 256 possible records)
+                if (pos < RCAP) s_rec[pos] = mine[it];                      // (the plan only sends glyphs with <= RCAP possible records)
             }
     }
-    rec_cnt = min(rec_cnt, 256u);
+    rec_cnt = min(rec_cnt, RCAP);
     __syncthreads();
 
     const float jscale = job.scale * 4.0f;
@@ -278,10 +281,11 @@ void cov4_kernel(const RenderArgs A)
     // every lane keeps the row ranges of its records in registers for all its bands: records RPL*lane ...
     // (consecutive, so the record index grows along the pair sequence and the marker decode is a max-scan)
     const bool few = rec_cnt <= 128u;              // workgroup-uniform: two records per lane are enough
-    uint32_t rra[4], rre[4];
+    const uint32_t per = few ? 2u : (uint32_t)RPL;
+    uint32_t rra[RPL], rre[RPL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t k = (few ? 2u : 4u) * lane + (uint32_t)i;
+    for (int i = 0; i < RPL; ++i) {
+        const uint32_t k = per * lane + (uint32_t)i;
         const bool have = k < rec_cnt && (!few || i < 2);
         const uint32_t f = s_rec[have ? k : 0u].fr;
         rra[i] = have ? (f & 0x7ffu) : 1u;
@@ -296,7 +300,7 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *s_E = wregion;
 
 #if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 5
-    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[1] + rra[2] + rre[3] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
+    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[1] + rra[RPL - 2] + rre[RPL - 1] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
 #endif
     for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
         const uint32_t band = band0 + wave;
@@ -318,12 +322,12 @@ void cov4_kernel(const RenderArgs A)
         uint32_t rr0 = 0;                          // first row (in the band) not laid out yet
         while (rr0 < 64u) {
             uint32_t span = 64u - rr0;
-            uint32_t c[4], r0[4], csum, incl, tot;
+            uint32_t c[RPL], r0[RPL], csum, incl, tot;
             for (;;) {
                 const uint32_t lo = row_b0 + rr0, hi = lo + span;
                 csum = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < RPL; ++i) {
                     r0[i] = max(rra[i], lo);
                     const uint32_t r1 = min(rre[i], hi);
                     c[i] = r1 > r0[i] ? r1 - r0[i] : 0u;
@@ -339,15 +343,17 @@ void cov4_kernel(const RenderArgs A)
                 if (C4_PCAP >= 512 || lane < C4_PCAP / 8) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
                 c4_wave_lds_sync();
                 uint32_t off = incl - csum;
-                uint32_t ro[4];
+                uint32_t ro[RPL];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (c[i]) s_pairs[off] = (uint16_t)((few ? 2u : 4u) * lane + (uint32_t)i + 1u);
+                for (int i = 0; i < RPL; ++i) {
+                    if (c[i]) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
                     ro[i] = (r0[i] - row_b0 - off) & 0xffffu;
                     off += c[i];
                 }
+                // my records' row offsets sit side by side: one store
                 if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
-                else *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
                 c4_wave_lds_sync();
                 const uint32_t npairs = tot;
                 // one pair per lane per trip; the marker max-scan of the NEXT 64 pairs is issued before the
@@ -511,58 +517,65 @@ void cov4_kernel(const RenderArgs A)
             if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), 4u);
         }
         if (ovf_rows) {
-            // ---- over-full sample rows: every record of the glyph (in LDS, with its exact row range) is evaluated
-            // once (lane = record, 64 at a time) and broadcast; lane L keeps the winding of sample columns
-            // 16 L ..., i.e. 4 pixels, and adds their inside counts to E in difference form (one dword of 4 bytes)
-            const uint32_t n_all = rec_cnt;
+            // ---- over-full sample rows (more than CAP crossings): the direct sum.  Every record of mine whose row
+            // range holds the row is evaluated once more and adds its step to a row of 16-bit winding DIFFERENCES
+            // in LDS (w(j) = sum over i >= j of d[i]: d[J - 1] += step; the 2 KB next to E, free since the lists
+            // were pulled); a suffix sum (16 columns per lane + one wave scan) gives every sample column's winding,
+            // lane L turns its 4 pixels' non-zero counts into E's difference form (one dword of 4 bytes).
+            uint32_t *s_wd = reinterpret_cast<uint32_t *>(wregion + L::E);      // [NCOL / 2] x two int16 fields, bias 0x4000
+            static_assert(L::WAVE >= L::E + NCOL * 2u, "no room for the winding differences of an over-full row");
             unsigned long long todo = ovf_rows;
             while (todo) {
                 const uint32_t r = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
                 const uint32_t grow = row_b0 + r;
-                int w16[16];
+                for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
+                    reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
+                c4_wave_lds_sync();
 #pragma unroll
-                for (int q = 0; q < 16; ++q) w16[q] = 0;
-                for (uint32_t kb = 0; kb < n_all; kb += 64u) {
-                    const uint32_t k = kb + lane;
-                    bool ok = false;
-                    int J = 0, sgn = 0;
-                    if (k < n_all) {
-                        const Rec40 rk = s_rec[k];
-                        ok = grow >= (rk.fr & 0x7ffu) && grow < ((rk.fr >> 11) & 0x7ffu);    // the rows that accept this root
-                        if (ok) {
-                            const bool lin = (int32_t)rk.fr < 0;
-                            const float delta = cy_r * rk.a + rk.c1 - rk.c2;
-                            const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
-                            const float t = div_by_int(num, rk.a, rk.rden);
-                            const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
-                            const float dy = rk.a * t - rk.b;
-                            sgn = (int)((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1;
-                            J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                            while (s_cxp[J + 1] <= xx) ++J;
-                            while (s_cxp[J] > xx) --J;
-                        }
-                    }
-                    unsigned long long m = __ballot(ok && J > 0);
-                    while (m) {
-                        const int i = (int)__builtin_ctzll(m);
-                        m &= m - 1ull;
-                        const uint32_t sJ = (uint32_t)__builtin_amdgcn_readlane(J, i);
-                        const int ss = __builtin_amdgcn_readlane(sgn, i);
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) w16[q] += (16u * lane + (uint32_t)q < sJ) ? ss : 0;
+                for (int i = 0; i < RPL; ++i) {
+                    if (rra[i] <= grow && grow < rre[i]) {                  // the rows that accept this root (exact)
+                        const Rec40 rk = s_rec[per * lane + (uint32_t)i];
+                        const bool lin = (int32_t)rk.fr < 0;
+                        const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                        const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                        const float t = div_by_int(num, rk.a, rk.rden);
+                        const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                        const float dy = rk.a * t - rk.b;
+                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
+                        int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                        while (s_cxp[J + 1] <= xx) ++J;
+                        while (s_cxp[J] > xx) --J;
+                        if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
                     }
                 }
+                c4_wave_lds_sync();
+                int wl[16], tot = 0;
+                if (16u * lane < NCOL) {
+                    const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
+                    const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                    for (int c = 15; c >= 0; --c) {
+                        tot += (int)((dws[c >> 1] >> (16 * (c & 1))) & 0xffffu) - 0x4000;
+                        wl[c] = tot;                                        // columns c .. 15 of my 16
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) wl[c] = 0;
+                }
+                const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
+                const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);   // everything right of my 16 columns
                 int cq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    cq[q] = (w16[4 * q] != 0) + (w16[4 * q + 1] != 0) + (w16[4 * q + 2] != 0) + (w16[4 * q + 3] != 0);
+                    cq[q] = (wl[4 * q] + right != 0) + (wl[4 * q + 1] + right != 0) + (wl[4 * q + 2] + right != 0) + (wl[4 * q + 3] + right != 0);
                 int prev = __shfl_up(cq[3], 1);
                 if (lane == 0) prev = 0;
                 const uint32_t val = (uint32_t)(cq[0] - prev) + ((uint32_t)(cq[1] - cq[0]) << 8) +
                                      ((uint32_t)(cq[2] - cq[1]) << 16) + ((uint32_t)(cq[3] - cq[2]) << 24);
                 if (16u * lane < NCOL) atomicAdd(reinterpret_cast<uint32_t *>(s_E + (r >> 2) * L::EROW) + lane, val);
+                c4_wave_lds_sync();
             }
         }
         c4_wave_lds_sync();
@@ -615,32 +628,41 @@ void cov4_kernel(const RenderArgs A)
     }
 }
 
-size_t cov4_lds_bytes(int wlog) { return wlog == 4 ? C4Lds<4>::TOTAL : C4Lds<3>::TOTAL; }
+size_t cov4_lds_bytes(int wlog, int rpl)
+{
+    if (rpl == 4) return wlog == 4 ? C4Lds<4, 4>::TOTAL : C4Lds<3, 4>::TOTAL;
+    return wlog == 4 ? C4Lds<4, 8>::TOTAL : C4Lds<3, 8>::TOTAL;
+}
 uint32_t cov4_wg_waves() { return C4_WAVES; }
 uint32_t cov4_max_segments() { return 256u; }
 
-template <int WLOG>
+template <int WLOG, int RPL>
 static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
 {
-    const size_t lds = C4Lds<WLOG>::TOTAL + a.lds_pad;
+    const size_t lds = C4Lds<WLOG, RPL>::TOTAL + a.lds_pad;
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
         return hipGetLastError();
     };
-    if (a.kmax <= 8) return launch(cov4_kernel<WLOG, 8>);
-    if (a.kmax <= 16) return launch(cov4_kernel<WLOG, 16>);
-    return launch(cov4_kernel<WLOG, 32>);
+    if (a.kmax <= 8) return launch(cov4_kernel<WLOG, 8, RPL>);
+    if (a.kmax <= 16) return launch(cov4_kernel<WLOG, 16, RPL>);
+    return launch(cov4_kernel<WLOG, 32, RPL>);
 }
 
 // jobs: uniform cells (w a multiple of strip_w in {128, 256}, h a multiple of 16 and <= 256), 4 x 4 samples,
-// every glyph with <= 256 possible root records (checked by fr_plan_create)
-hipError_t launch_cov4(const RenderArgs &a, hipStream_t stream)
+// every glyph with <= 256 segments and <= rec_cap (256 or 512) possible root records (checked by fr_plan_create)
+hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, hipStream_t stream)
 {
     const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
-    if (a.strip_w == 256u) return cov4_launch_cap<4>(a, grid, stream);
-    if (a.strip_w == 128u) return cov4_launch_cap<3>(a, grid, stream);
+    if (rec_cap <= 256u) {
+        if (a.strip_w == 256u) return cov4_launch_cap<4, 4>(a, grid, stream);
+        if (a.strip_w == 128u) return cov4_launch_cap<3, 4>(a, grid, stream);
+    } else {
+        if (a.strip_w == 256u) return cov4_launch_cap<4, 8>(a, grid, stream);
+        if (a.strip_w == 128u) return cov4_launch_cap<3, 8>(a, grid, stream);
+    }
     return hipErrorInvalidValue;
 }
 
