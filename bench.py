@@ -244,12 +244,14 @@ def main():
             traffic = None
     if mode == fr.FR_SDF_U8:
         kname = "fr::render_kernel<COVERAGE_U8,1> + fr::sdf_kernel"
-    elif pstats["jobs_general"] == 0:
+    elif pstats["jobs_general"] == 0 and mode == fr.FR_COVERAGE_U8 and n == 4:
         kname = f"fr::cov4_kernel<{4 if wl['cell'] % 256 == 0 else 3},32>"
+    elif pstats["jobs_general"] == 0:
+        kname = f"fr::win1_kernel<{4 if wl['cell'] % 256 == 0 else 3},{mode_name}>"
     elif pstats["jobs_cov4"] == 0:
         kname = f"fr::render_kernel<{mode_name},{n}>"
     else:
-        kname = f"fr::cov4_kernel ({pstats['jobs_cov4']} jobs) + fr::render_kernel ({pstats['jobs_general']} jobs)"
+        kname = f"fr::{'cov4' if n == 4 else 'win1'}_kernel ({pstats['jobs_cov4']} jobs) + fr::render_kernel ({pstats['jobs_general']} jobs)"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": pixels * bpp, "kernel_ms": round(k_ms, 4), "build_id": fr.build_id()}

@@ -21,6 +21,7 @@ void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const u
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
 uint32_t render_wg_waves();
 hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, hipStream_t);
+hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
 hipError_t launch_sdf(const RenderArgs &, const int16_t *, const uint32_t *, uint32_t, uint32_t, int cull, hipStream_t);
@@ -417,12 +418,16 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     std::vector<uint32_t> order(n_jobs);
     uint32_t n_fast = 0;
     {
-        const bool mode_ok = ctx->cov4 && params->mode == FR_COVERAGE_U8 && n == 4u && (sw == 128u || sw == 256u);
+        // (cov4_kernel: 16 samples per pixel; win1_kernel: the one-sample modes, cells up to 1024 pixels tall)
+        const bool one = params->mode == FR_WINDING_I16 || params->mode == FR_GRAY_DEBUG || params->mode == FR_MASK_NONZERO ||
+                         (params->mode == FR_COVERAGE_U8 && n == 1u);
+        const bool mode_ok = ctx->cov4 && (sw == 128u || sw == 256u) && ((params->mode == FR_COVERAGE_U8 && n == 4u) || one);
+        const uint32_t max_h_fast = one ? 1024u : 256u;
         std::vector<uint32_t> mid, slow;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             const fr_job &jb = jobs[j];
             const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
-            const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= 256u &&
+            const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= max_h_fast &&
                               nsg <= fr::cov4_max_segments();
             if (fast && gs->h_root_bound[jb.glyph] <= 256u) order[n_fast++] = j;
             else if (fast) mid.push_back(j);           // (<= 256 segments: <= 512 candidate roots)
@@ -553,7 +558,9 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.job_seg = plan->d_job_seg + 2u * (size_t)first;
         a.n_jobs = cnt; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
         split_bands(fr::cov4_wg_waves(), cnt, plan->fast_bands, plan->fast_strips);
-        HIP_TRY(fr::launch_cov4(a, part ? 512u : 256u, plan->ctx->stream));
+        const int pm = plan->params.mode;
+        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, part ? 512u : 256u, plan->ctx->stream));
+        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), part ? 512u : 256u, plan->ctx->stream));
     }
     if (n_gen) {
         a.jobs = plan->d_jobs + n_fast;

@@ -1,0 +1,168 @@
+// fr_c4.hpp — what cov4_kernel (fr_cov4.hip, 16 samples per pixel) and win1_kernel (fr_win1.hip, 1 sample per pixel)
+// share: the 40-byte root record, wave64 DPP scans, the workgroup set-up (records with exact row ranges + cx table).
+#pragma once
+#include "fr_records.hpp"
+
+namespace fr {
+
+#ifndef FR_C4_WAVES
+#define FR_C4_WAVES 4
+#endif
+#ifndef FR_C4_OCC
+#define FR_C4_OCC 4
+#endif
+#ifndef FR_C4_PCAP
+#define FR_C4_PCAP 384
+#endif
+#ifndef FR_C4_LSTRIDE
+#define FR_C4_LSTRIDE 36
+#endif
+// PCAP: (record, row) pairs laid out per round (a multiple of 64).  LSTRIDE: u16 slots per row list — 32 kept + the
+// dump slot + padding; a multiple of 4 (8-byte rows), 16-byte rows when a multiple of 8
+enum { C4_WAVES = FR_C4_WAVES, C4_PCAP = FR_C4_PCAP, C4_LSTRIDE = FR_C4_LSTRIDE };
+// 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
+__device__ __forceinline__ uint4 c4_ld16(const uint16_t *p)
+{
+    if ((C4_LSTRIDE * 2) % 16 == 0) return *reinterpret_cast<const uint4 *>(p);
+    const uint2 a = reinterpret_cast<const uint2 *>(p)[0], b = reinterpret_cast<const uint2 *>(p)[1];
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void c4_st16(uint16_t *p, uint4 v)
+{
+    if ((C4_LSTRIDE * 2) % 16 == 0) { *reinterpret_cast<uint4 *>(p) = v; return; }
+    reinterpret_cast<uint2 *>(p)[0] = make_uint2(v.x, v.y);
+    reinterpret_cast<uint2 *>(p)[1] = make_uint2(v.z, v.w);
+}
+
+// 40-byte root record of the cov4 kernel (LDS only)
+struct __attribute__((aligned(8))) Rec40 {
+    float a;        // quadratic: p0y - 2 p1y + p2y (:48); linear (a == 0 branch): the divisor p2y - p0y (:51)
+    float b;        // quadratic: p0y - p1y;               linear: p0y
+    float c1, c2;   // quadratic: p1y^2, p0y p2y (:58);    linear: 0
+    float ax, bx, p0x;   // (:53 / :65)
+    float rden;     // RN(1 / a)
+    float sgn;      // +1 for the t+ root, -1 for t-  (sqrt * +-1 is exact: B - sqrt == B + (-sqrt))
+    uint32_t fr;    // ra | re << 11 | cb << 22 | zb << 24 | linear << 31: sample rows [ra, re) accept the root;
+                    // the crossing's step code is (dy > 0) ? zb : cb   (2: +1, 0: -1; :55, :68)
+};
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t c4_dpp0(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t c4_dppm(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t c4_wave_incl_add(uint32_t x)
+{
+    x += c4_dppm<0x111, 0xf>(x);
+    x += c4_dppm<0x112, 0xf>(x);
+    x += c4_dppm<0x114, 0xf>(x);
+    x += c4_dppm<0x118, 0xf>(x);
+    x += c4_dppm<0x142, 0xa>(x);
+    x += c4_dppm<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t c4_wave_incl_max(uint32_t x)
+{
+    x = max(x, c4_dppm<0x111, 0xf>(x));
+    x = max(x, c4_dppm<0x112, 0xf>(x));
+    x = max(x, c4_dppm<0x114, 0xf>(x));
+    x = max(x, c4_dppm<0x118, 0xf>(x));
+    x = max(x, c4_dppm<0x142, 0xa>(x));
+    x = max(x, c4_dppm<0x143, 0xc>(x));
+    return x;
+}
+// select on a wave mask held in SGPRs — the VOP3 form, whose cost does not depend on what wrote the mask
+// (a VOP2 v_cndmask reading a VCC that is not fresh costs 3-5 vector instructions: profiles/r02/issue_model3.txt)
+__device__ __forceinline__ uint32_t c4_sel(unsigned long long m, uint32_t if_set, uint32_t if_clear)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float c4_self(unsigned long long m, float if_set, float if_clear)
+{
+    return __builtin_bit_cast(float, c4_sel(m, __builtin_bit_cast(uint32_t, if_set), __builtin_bit_cast(uint32_t, if_clear)));
+}
+__device__ __forceinline__ void c4_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+
+// Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW (<= 256 segments) with the
+// exact range of this cell's sample rows that accept each (fr_records.hpp), compacted into s_rec (<= RCAP kept), and
+// the padded table of the strip's exact sample abscissae.  Two workgroup barriers.  -> number of records.
+// N: samples per pixel axis (4: cov4_kernel, 1: win1_kernel); NCOL: sample columns of the strip.
+template <uint32_t NW, uint32_t RCAP, int N, uint32_t NCOL>
+__device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
+                                             int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t Hs = job.h * (uint32_t)N;
+    constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
+    Rec40 mine[CPT];
+    unsigned long long lm[CPT];
+#pragma unroll
+    for (uint32_t it = 0; it < CPT; ++it) {
+        const uint32_t c = tid + it * 64u * NW;
+        bool live = false;
+        lm[it] = 0ull;
+        if (it > 0 && it * 64u * NW >= 2u * nseg) continue;                 // workgroup-uniform: no second candidate
+        if (c < 2u * nseg) {
+            Rec r;
+            RowGeom geo;
+            geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+            build_record_rows(A.seg_pts + 6u * (size_t)(seg0 + (c >> 1)), c & 1u, geo, r);
+            const uint32_t ra = __builtin_bit_cast(uint32_t, r.lo), re = __builtin_bit_cast(uint32_t, r.hi);
+            live = ra < re;
+            const bool lin = (int32_t)r.flags < 0;
+            mine[it].a = lin ? r.c1 : r.a;
+            mine[it].b = r.b; mine[it].c1 = lin ? 0.0f : r.c1; mine[it].c2 = r.c2;
+            mine[it].ax = r.ax; mine[it].bx = r.bx; mine[it].p0x = r.p0x; mine[it].rden = r.rden;
+            mine[it].sgn = r.sqsign ? -1.0f : 1.0f;
+            const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
+            mine[it].fr = ra | (re << 11) | (cb << 22) | (zb << 24) | (lin ? 0x80000000u : 0u);
+        }
+        lm[it] = __ballot(live);
+        if (lane == 0) s_wcnt[it * NW + wave] = (uint32_t)__popcll(lm[it]);
+    }
+    // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
+    const int32_t min_xs = job.min_x + (int32_t)x0s;
+    for (uint32_t j = tid; j < NCOL; j += 64u * NW)
+        s_cxp[1u + j] = ((float)(min_xs + (int32_t)(j / (uint32_t)N)) + sub_off((int)(j % (uint32_t)N), N, phase)) / job.scale;
+    if (tid == 2) s_cxp[0] = -__builtin_inff();
+    if (tid == 3) s_cxp[1u + NCOL] = __builtin_inff();
+    __syncthreads();
+    uint32_t rec_cnt = 0;
+    {
+        uint32_t my_base[CPT];
+#pragma unroll
+        for (uint32_t it = 0; it < CPT; ++it) my_base[it] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < CPT * NW; ++q) {
+            if (q >= NW && q / NW * 64u * NW >= 2u * nseg) continue;        // (never written)
+            const uint32_t c = s_wcnt[q];
+#pragma unroll
+            for (uint32_t it = 0; it < CPT; ++it) my_base[it] += (q < it * NW + wave) ? c : 0u;
+            rec_cnt += c;
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < CPT; ++it)
+            if ((lm[it] >> lane) & 1ull) {
+                const uint32_t pos = my_base[it] + (uint32_t)__popcll(lm[it] & ((1ull << lane) - 1ull));
+                if (pos < RCAP) s_rec[pos] = mine[it];                      // (the plan only sends glyphs with <= RCAP possible records)
+            }
+    }
+    rec_cnt = min(rec_cnt, RCAP);
+    __syncthreads();
+    return rec_cnt;
+}
+
+}  // namespace fr

@@ -1,0 +1,393 @@
+// fr_win1.hip — the reference's own products at one sample per pixel: Image.Winding (int16 winding numbers),
+// renderGlyph's gray map clamp(w * 20 + 100) (/root/reference/src/tools/render_glyph.zig:28) and the non-zero mask
+// (:29), for atlas cells (uniform plans); the general render_kernel keeps every other shape.
+//
+// Same integers as glyphWindingAt per pixel (:35-73): winding(x) = sum over accepted roots of step [x < J].
+// With one sample per pixel there is no inside/outside rule to apply per sample row, so nothing has to be sorted:
+// every crossing adds its step to ONE byte of a row of winding DIFFERENCES (LDS, ds_add_u32 on the dword holding
+// it) straight from the evaluation — d[J - 1] += step, w(x) = sum over i >= x of d[i] — and a window lane
+// integrates 16 pixels exactly as cov4_kernel integrates coverage (multiply by 0x01010101 per dword, 3-step chain,
+// 4-step DPP scan across the 16 windows of a row).  The row is stored right to left (byte q = NCOL - 1 - x) so the
+// suffix sum is a prefix sum; a lane reverses its 16 bytes before the store.  Bytes carry a bias (32 in LDS, 96
+// after the scans) and hold |w| <= 31: a row with more than 31 crossings (it alone could leave that range) takes
+// the direct path — 16-bit differences, suffix scan, pixels written from there.  No lists, no sort, no toggles:
+// per 4 KB of gray output about half the vector instructions of cov4_kernel's 16-sample pixel.
+#include "fr_c4.hpp"
+
+namespace fr {
+
+enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2 };
+enum { W1_ROWS = 16 };
+
+template <int WLOG, int RPL>
+struct W1Lds {
+    static constexpr uint32_t NCOL = 16u << WLOG;                           // sample columns = pixels of a strip
+    static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;
+    static constexpr uint32_t RCAP = 64u * RPL;
+    static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
+    static constexpr uint32_t PCAP = RCAP > 256u ? RCAP : 256u;             // pairs per round (one row has <= RCAP)
+    static constexpr uint32_t EROW = NCOL + 16u;
+    static constexpr uint32_t E = W1_ROWS * EROW;
+    // per wave: E | markers [PCAP] u16 (later: one row of 16-bit differences) | cy [16] | cnt [16] | roff [RCAP] i16
+    static constexpr uint32_t OFF_PAIRS = E;
+    static constexpr uint32_t OFF_CY = OFF_PAIRS + PCAP * 2u;
+    static constexpr uint32_t OFF_CNT = OFF_CY + 64u;
+    static constexpr uint32_t OFF_ROFF = OFF_CNT + 64u;
+    static constexpr uint32_t WAVE = (OFF_ROFF + RCAP * 2u + 15u) & ~15u;
+    static constexpr uint32_t OFF_WAVES = CX + REC;
+    static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
+    static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
+};
+
+__device__ __forceinline__ uint32_t w1_gray(int w)
+{
+    const int v = w * 20 + 100;                     // render_glyph.zig:28
+    return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+template <int WLOG, int MODE, int RPL>
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
+void win1_kernel(const RenderArgs A)
+{
+    using L = W1Lds<WLOG, RPL>;
+    constexpr uint32_t NW = C4_WAVES;
+    constexpr uint32_t RCAP = L::RCAP;
+    constexpr uint32_t NCOL = L::NCOL;              // pixels of a strip
+    constexpr uint32_t NWIN = 1u << WLOG;
+    constexpr uint32_t PCAP = L::PCAP;
+    constexpr uint32_t ESZ = (MODE == MODE1_WINDING_I16) ? 2u : 1u;
+    extern __shared__ __align__(16) unsigned char smem[];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
+    if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
+    if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
+    const uint32_t jidx = bid;
+    const Job job = A.jobs[jidx];
+    const uint32_t x0s = strip * NCOL;
+    const uint32_t band_first = bgrp * A.bands_per_wg;                      // bands of 16 pixel rows
+    if (band_first * W1_ROWS >= job.h || x0s >= job.w) return;             // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, job.h / W1_ROWS);
+    const int phase = A.phase_center;
+    const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
+
+    float *s_cxp = reinterpret_cast<float *>(smem);
+    Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
+    unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
+    uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
+
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt);
+    const int32_t min_xs = job.min_x + (int32_t)x0s;
+    const float jscale = job.scale;
+    const float soff = phase ? 0.5f : 0.0f;
+    const float joff = (float)min_xs + soff - 1.0f;
+    const float ncolf = (float)NCOL;
+    const bool few = rec_cnt <= 128u;
+    const uint32_t per = few ? 2u : (uint32_t)RPL;
+    uint32_t rra[RPL], rre[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const uint32_t k = per * lane + (uint32_t)i;
+        const bool have = k < rec_cnt && (!few || i < 2);
+        const uint32_t f = s_rec[have ? k : 0u].fr;
+        rra[i] = have ? (f & 0x7ffu) : 1u;
+        rre[i] = have ? ((f >> 11) & 0x7ffu) : 0u;
+    }
+
+    unsigned char *s_E = wregion;
+    uint16_t *s_pairs = reinterpret_cast<uint16_t *>(wregion + L::OFF_PAIRS);
+    float *s_cy = reinterpret_cast<float *>(wregion + L::OFF_CY);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(wregion + L::OFF_CNT);
+    int16_t *s_roff = reinterpret_cast<int16_t *>(wregion + L::OFF_ROFF);
+    const uint32_t wx = lane & (NWIN - 1u);
+
+    for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
+        const uint32_t band = band0 + wave;
+        if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
+        const uint32_t y0 = band * W1_ROWS;         // first pixel row = first sample row of my band
+        // ray height of row `lane & 15`: cy = (f32(max_y - y) - off) / scale   (:27)
+        const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane & 15u))) - soff) / job.scale;
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(s_E);
+            const uint4 bias = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+            constexpr uint32_t NZ = L::E / 16u;
+#pragma unroll
+            for (uint32_t q = 0; q < (NZ + 63u) / 64u; ++q)
+                if (NZ % 64u == 0u || lane + 64u * q < NZ) z[lane + 64u * q] = bias;
+        }
+        if (lane < 16u) { s_cy[lane] = cy; s_cnt[lane] = 0u; }
+
+        // ---- layout + evaluation: rounds of at most PCAP (record, row) pairs over a span of the band's 16 rows
+        uint32_t rr0 = 0;
+        while (rr0 < W1_ROWS) {
+            uint32_t span = W1_ROWS - rr0;
+            uint32_t c[RPL], r0[RPL], csum, incl, tot;
+            for (;;) {
+                const uint32_t lo = y0 + rr0, hi = lo + span;
+                csum = 0;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    r0[i] = max(rra[i], lo);
+                    const uint32_t r1 = min(rre[i], hi);
+                    c[i] = r1 > r0[i] ? r1 - r0[i] : 0u;
+                    csum += c[i];
+                }
+                incl = c4_wave_incl_add(csum);
+                tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (tot <= PCAP || span == 1u) break;
+                span >>= 1;
+            }
+            if (tot) {
+                if (PCAP >= 512u || lane < PCAP / 8u) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
+                c4_wave_lds_sync();
+                uint32_t off = incl - csum;
+                uint32_t ro[RPL];
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    if (c[i]) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
+                    ro[i] = (r0[i] - y0 - off) & 0xffffu;
+                    off += c[i];
+                }
+                if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
+                else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                c4_wave_lds_sync();
+                const uint32_t npairs = tot;
+                uint32_t k_cur = c4_wave_incl_max((uint32_t)s_pairs[lane]);
+                uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+                for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
+                    const uint32_t pn = min(p0 + 64u + lane, PCAP - 1u);
+                    const uint32_t s_next = c4_wave_incl_max((uint32_t)s_pairs[pn]);
+                    {
+                        const uint32_t p = p0 + lane, k1 = k_cur;
+                        const bool livep = p < npairs;
+                        const uint32_t row = ((uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u])) & 15u;
+                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
+                        const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
+                        const float cyr = s_cy[row];
+                        // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67); the row
+                        // range is exactly the set of rows on which the reference accepts this root (fr_records.hpp)
+                        const float delta = cyr * r.a + r.c1 - r.c2;
+                        const float sq = sqrt_rn(delta);
+                        const float numq = r.b + sq * r.sgn, numl = cyr - r.b;
+                        const unsigned long long linm = __builtin_amdgcn_sicmp((int32_t)r.fr, 0, 40 /* ICMP_SLT */);
+                        const float num = c4_self(linm, numl, numq);
+                        const float t = div_by_int(num, r.a, r.rden);
+                        const float xx = (r.ax * t + r.bx) * t + r.p0x;
+                        const float dy = r.a * t - r.b;
+                        const uint32_t cb = (r.fr >> 22) & 3u, zb = (r.fr >> 24) & 3u;
+                        const uint32_t code = (dy > 0.0f) ? zb : cb;
+                        // J = #{ x in [0, NCOL) : cx(x) <= xx }   (:54, :66)
+                        const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                        int J = (int)gf;
+                        {
+                            const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
+                            const bool good = (c0 <= xx) & (xx < c1);
+                            if (!good & livep) {
+                                while (s_cxp[J + 1] <= xx) ++J;
+                                while (s_cxp[J] > xx) --J;
+                            }
+                        }
+                        if (livep & (J > 0)) {
+                            // d[J - 1] += step, stored right to left: byte q = NCOL - J of the row
+                            const uint32_t q = NCOL - (uint32_t)J;
+                            atomicAdd(reinterpret_cast<uint32_t *>(s_E + row * L::EROW + (q & ~3u)), (code - 1u) << (8u * (q & 3u)));
+                            atomicAdd(&s_cnt[row], 1u);
+                        }
+                    }
+                    k_cur = max(s_next, carry);
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+                }
+                c4_wave_lds_sync();
+            }
+            rr0 += span;
+        }
+        c4_wave_lds_sync();
+        const uint32_t cnt = s_cnt[lane & 15u];
+        unsigned char *const out_band = reinterpret_cast<unsigned char *>(A.out) +
+                                        (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
+        const size_t row_bytes = (size_t)A.out_stride * ESZ;
+        if ((__ballot(cnt != 0u) & 0xffffull) == 0ull) {
+            // no crossing on any of my 16 rows: every winding is 0
+            const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
+            const uint4 v = make_uint4(bg, bg, bg, bg);
+            for (uint32_t yl = lane >> WLOG; yl < W1_ROWS; yl += (64u >> WLOG)) {
+                unsigned char *dst = out_band + (size_t)yl * row_bytes + 16u * ESZ * wx;
+                __builtin_memcpy(dst, &v, 16);
+                if (ESZ == 2u) __builtin_memcpy(dst + 16, &v, 16);
+            }
+            c4_wave_lds_sync();
+            continue;
+        }
+        // rows with more than 31 crossings could leave the byte range: the direct path, pixels stored from here
+        const uint32_t ovf_rows = (uint32_t)(__ballot(cnt > 31u) & 0xffffull);
+        if (ovf_rows) {
+            uint32_t *s_wd = reinterpret_cast<uint32_t *>(s_pairs);          // [NCOL / 2] x two int16 fields, bias 0x4000
+            static_assert(PCAP * 2u >= NCOL * 2u, "no room for the 16-bit winding differences of a row");
+            uint32_t todo = ovf_rows;
+            while (todo) {
+                const uint32_t r = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
+                const uint32_t grow = y0 + r;
+                for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
+                    reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
+                c4_wave_lds_sync();
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    if (rra[i] <= grow && grow < rre[i]) {
+                        const Rec40 rk = s_rec[per * lane + (uint32_t)i];
+                        const bool lin = (int32_t)rk.fr < 0;
+                        const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                        const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                        const float t = div_by_int(num, rk.a, rk.rden);
+                        const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                        const float dy = rk.a * t - rk.b;
+                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1u;
+                        int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                        while (s_cxp[J + 1] <= xx) ++J;
+                        while (s_cxp[J] > xx) --J;
+                        if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
+                    }
+                }
+                c4_wave_lds_sync();
+                int wl[16], tot = 0;
+                if (16u * lane < NCOL) {
+                    const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
+                    const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                    for (int cc = 15; cc >= 0; --cc) {
+                        tot += (int)((dws[cc >> 1] >> (16 * (cc & 1))) & 0xffffu) - 0x4000;
+                        wl[cc] = tot;
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) wl[cc] = 0;
+                }
+                const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
+                const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);
+                if (16u * lane < NCOL) {
+                    unsigned char *dst = out_band + (size_t)r * row_bytes + 16u * ESZ * lane;
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) {
+                        const int w = wl[cc] + right;
+                        if (MODE == MODE1_WINDING_I16) reinterpret_cast<int16_t *>(dst)[cc] = (int16_t)w;
+                        else dst[cc] = (unsigned char)((MODE == MODE1_GRAY_DEBUG) ? w1_gray(w) : (w != 0 ? 255u : 0u));
+                    }
+                }
+                c4_wave_lds_sync();
+            }
+        }
+
+        // ---- windows: lane = 16 pixels of one pixel row (right to left in LDS); integrate, map, store
+        constexpr uint32_t K1 = 0x01010101u;
+#pragma unroll
+        for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) {
+            const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
+            const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
+            // bytes 32 + d: inclusive prefix inside each dword gives 32 (i + 1) + sums; then a bias of 64 per byte
+            uint32_t x0 = e.x * K1, x1 = e.y * K1, x2 = e.z * K1, x3 = e.w * K1;
+            x0 += 0xbfe00020u;                                              // + 32, 0, - 32, - 64 per byte
+            x1 = x1 + __builtin_amdgcn_perm(x0, x0, 0x03030303u) - 0x80604020u;
+            x2 = x2 + __builtin_amdgcn_perm(x1, x1, 0x03030303u) - 0x80604020u;
+            x3 = x3 + __builtin_amdgcn_perm(x2, x2, 0x03030303u) - 0x80604020u;
+            const uint32_t T = (x3 >> 24) - 64u;                            // my window's total (signed)
+            uint32_t inc = T;
+            if (WLOG == 4) {
+                inc += c4_dpp0<0x111>(inc);
+                inc += c4_dpp0<0x112>(inc);
+                inc += c4_dpp0<0x114>(inc);
+                inc += c4_dpp0<0x118>(inc);
+            } else {
+                uint32_t s;
+                s = c4_dpp0<0x111>(inc); inc += (wx >= 1u) ? s : 0u;
+                s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
+                s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u;
+            }
+            const uint32_t cin = inc - T + 32u;                             // winding entering my window, + 32: in [1, 63]
+            const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
+            x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 96 + w
+            // back to pixel order: byte q of the row holds pixel NCOL - 1 - q
+            const uint32_t p0 = __builtin_amdgcn_perm(x3, x3, 0x00010203u), p1 = __builtin_amdgcn_perm(x2, x2, 0x00010203u);
+            const uint32_t p2 = __builtin_amdgcn_perm(x1, x1, 0x00010203u), p3 = __builtin_amdgcn_perm(x0, x0, 0x00010203u);
+            if ((ovf_rows >> prow) & 1u) continue;                          // stored by the direct path above
+            unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(NCOL - 16u - 16u * wx) * ESZ;
+            if (MODE == MODE1_MASK) {
+                auto m4 = [](uint32_t x) -> uint32_t {
+                    const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
+                    const uint32_t nz = ((z + 0x7f7f7f7fu) | z) & 0x80808080u;
+                    return nz | (nz - (nz >> 7));                           // 0x80 -> 0xff
+                };
+                const uint4 v = make_uint4(m4(p0), m4(p1), m4(p2), m4(p3));
+                __builtin_memcpy(dst, &v, 16);
+            } else if (MODE == MODE1_GRAY_DEBUG) {
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                auto g2 = [](uint32_t h) -> uint32_t {                      // two 16-bit lanes holding 96 + w
+                    u16x2 v = __builtin_bit_cast(u16x2, h);
+                    v = __builtin_elementwise_sub_sat(v, (u16x2){91, 91});  // clamp(w, -5, ..) + 5
+                    v = __builtin_elementwise_min(v, (u16x2){13, 13});      // .. clamp(w, -5, 8) + 5
+                    v = v * (u16x2){20, 20};                                // (w' * 20 + 100)
+                    v = __builtin_elementwise_min(v, (u16x2){255, 255});    // 260 -> 255 (:28)
+                    return __builtin_bit_cast(uint32_t, v);
+                };
+                auto g4 = [&](uint32_t x) -> uint32_t { return g2(x & 0x00ff00ffu) | (g2((x >> 8) & 0x00ff00ffu) << 8); };
+                const uint4 v = make_uint4(g4(p0), g4(p1), g4(p2), g4(p3));
+                __builtin_memcpy(dst, &v, 16);
+            } else {
+                typedef short i16x2 __attribute__((ext_vector_type(2)));
+                auto w2 = [](uint32_t h) -> uint32_t {
+                    const i16x2 v = __builtin_bit_cast(i16x2, h) - (i16x2){96, 96};
+                    return __builtin_bit_cast(uint32_t, v);
+                };
+                uint32_t o[8];
+                const uint32_t ps[4] = {p0, p1, p2, p3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t lo = w2(ps[q] & 0x00ff00ffu), hi = w2((ps[q] >> 8) & 0x00ff00ffu);   // pixels 0, 2 | 1, 3
+                    o[2 * q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                    o[2 * q + 1] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+                }
+                const uint4 va = make_uint4(o[0], o[1], o[2], o[3]), vb = make_uint4(o[4], o[5], o[6], o[7]);
+                __builtin_memcpy(dst, &va, 16);
+                __builtin_memcpy(dst + 16, &vb, 16);
+            }
+        }
+        c4_wave_lds_sync();                        // E is re-initialised by the next band
+    }
+}
+
+uint32_t win1_band_rows() { return W1_ROWS; }
+
+template <int WLOG, int RPL>
+static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hipStream_t stream)
+{
+    const size_t lds = W1Lds<WLOG, RPL>::TOTAL + a.lds_pad;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
+        return hipGetLastError();
+    };
+    if (mode == MODE1_WINDING_I16) return launch(win1_kernel<WLOG, MODE1_WINDING_I16, RPL>);
+    if (mode == MODE1_GRAY_DEBUG) return launch(win1_kernel<WLOG, MODE1_GRAY_DEBUG, RPL>);
+    return launch(win1_kernel<WLOG, MODE1_MASK, RPL>);
+}
+
+// jobs: uniform cells (w a multiple of strip_w in {128, 256}, h a multiple of 16 and <= 1024), one sample per pixel,
+// glyphs with <= 256 segments and <= rec_cap possible root records.  mode: 0 winding_i16, 1 gray_debug, 2 mask
+hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream)
+{
+    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
+    if (rec_cap <= 256u) {
+        if (a.strip_w == 256u) return win1_launch_mode<4, 4>(a, mode, grid, stream);
+        if (a.strip_w == 128u) return win1_launch_mode<3, 4>(a, mode, grid, stream);
+    } else {
+        if (a.strip_w == 256u) return win1_launch_mode<4, 8>(a, mode, grid, stream);
+        if (a.strip_w == 128u) return win1_launch_mode<3, 8>(a, mode, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fr

@@ -193,6 +193,48 @@ def test_cov4_kernel_strips_combs_strokes_and_mixed_plans(ctx, oracle):
     assert np.array_equal(_render_opt(ctx, gs, jobs, shape, 4, True), ref)
 
 
+@pytest.mark.parametrize("mode,omode", MODES)
+def test_win1_kernel_matches_the_oracle(ctx, oracle, mode, omode):
+    """win1_kernel (fr_win1.hip: one sample per pixel, crossings added straight into a row of winding
+    differences, no sort): Image.Winding values, renderGlyph's gray map and the non-zero mask on 256- and
+    128-pixel cells — synthetic, stroke-dense (windings up to 4+), combs (rows of 80 crossings: the direct
+    path), two strips per cell, bands split over workgroups — against the oracle and the general kernel"""
+    gl = []
+    for teeth in (40, 6):
+        cs, box = comb_glyph(teeth)
+        gl.append(Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs]))
+    parts = [synth_glyphset(3, 128, first_index=61), stroke_glyphset(3, 160, first_index=62), synth_glyphset(2, 250, first_index=63)]
+    gl += [p.glyph(i) for p in parts for i in range(len(p))]
+    gs = GlyphSet(gl)
+    dt = np.int16 if mode == fr.FR_WINDING_I16 else np.uint8
+    for cell, center in ((256, False), (128, True)):
+        jobs = cell_jobs(gs, cell, cell - 20, 2048, 4)
+        shape = atlas_shape(len(gs), cell, 4)
+        ref = np.full(shape, 7, dt)
+        oracle.render_batch(gs, jobs, omode, ref, 1, center, 16)
+        for opts in ({}, {"cov4": 0}, {"min_wgs": 1 << 20}):
+            try:
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                dgs = fr.DeviceGlyphSet(ctx, gs)
+                got = np.full(shape, 7, dt)
+                plan = fr.Plan(dgs, jobs, mode, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+                assert plan.stats()["jobs_cov4"] == (0 if "cov4" in opts else len(gs))
+                plan.close()
+                rg.render_batch(dgs, jobs, mode, got, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+                dgs.close()
+            finally:
+                ctx.set_option("cov4", 1); ctx.set_option("min_wgs", 2048)
+            assert np.array_equal(got, ref), (cell, opts)
+    if mode == fr.FR_WINDING_I16:
+        assert ref.max() >= 2 and ref.min() < 0
+    # a 512 x 48 cell: two 256-pixel strips, three bands of 16 rows
+    sg = synth_glyphset(2, 64, first_index=880)
+    rows = [(i, int(np.floor(sg.boxes[i][0] * 0.25)), int(np.ceil(sg.boxes[i][3] * 0.25)) - 200, 512, 48, 0, 48 * i, np.float32(0.25)) for i in range(2)]
+    got, ref = _batch_both(ctx, oracle, sg, rg.make_jobs(rows), mode, (96, 512), 1, False, threads=16)
+    assert np.array_equal(got, ref)
+
+
 def test_cov4_equals_general_kernel_on_2048_cells(ctx):
     """2 048 glyphs x 256^2 (a tenth of configs[2]) through cov4_kernel and through the general kernel:
     identical bytes (the general kernel is the one the oracle checks at small sizes)"""
