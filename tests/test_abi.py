@@ -110,3 +110,78 @@ def test_qoi_writer_decodes_with_an_independent_decoder(oracle):
     gray[4:9] = 200
     dec = np.asarray(PILImage.open(io.BytesIO(qoi.saveRGB(gray))).convert("RGB"))
     assert np.array_equal(dec, np.repeat(gray[:, :, None], 3, 2))
+
+
+def _c_class(t: str) -> str:
+    t = t.strip()
+    if "*" in t or "[" in t:
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).split()
+    base = " ".join(w for w in t[:-1]) if len(t) > 1 else t[0]      # drop the parameter name
+    base = base.strip() or t[0]
+    return {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint16_t": "u16", "int16_t": "i16", "uint8_t": "u8",
+            "uint64_t": "u64", "int64_t": "i64", "size_t": "usize", "float": "f32", "void": "void"}[base]
+
+
+def _zig_class(t: str) -> str:
+    t = t.strip()
+    if t.startswith(("*", "?*", "[*", "?[*")):
+        return "ptr"
+    return {"c_int": "i32", "i32": "i32", "u32": "u32", "u16": "u16", "i16": "i16", "u8": "u8", "u64": "u64", "i64": "i64",
+            "usize": "usize", "f32": "f32", "void": "void"}[t]
+
+
+def _split_params(p: str):
+    out, depth, cur = [], 0, ""
+    for ch in p:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out if x.strip() and x.strip() != "void"]
+
+
+def test_zig_binding_matches_the_header():
+    """bindings/fr_raster.zig cannot be compiled here (no zig toolchain), so it is pinned textually: every function
+    of include/fr_raster.h is declared `extern "c"` with the same name, the same number of parameters and the same
+    integer / float / pointer classes (and return class); enums and the two structs carry the header's values / fields."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fr_raster.h")).read(), flags=re.S)
+    zig = open(os.path.join(ROOT, "bindings", "fr_raster.zig")).read()
+    c_fns = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?[A-Za-z_0-9]+\s*\*?)\s*(fr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.M | re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        c_fns[name] = ("ptr" if "*" in ret else _c_class(ret + " x"), [_c_class(q) for q in _split_params(params)])
+    z_fns = {}
+    for m in re.finditer(r'pub extern "c" fn (fr_[a-z0-9_]+)\((.*?)\) ([^;]+);', zig):
+        name, params, ret = m.group(1), m.group(2), m.group(3)
+        z_fns[name] = (_zig_class(ret), [_zig_class(q.split(":", 1)[1]) for q in _split_params(params)])
+    assert sorted(c_fns) == _declared_symbols()
+    assert sorted(z_fns) == sorted(c_fns), sorted(set(c_fns) ^ set(z_fns))
+    for name in c_fns:
+        assert z_fns[name] == c_fns[name], (name, z_fns[name], c_fns[name])
+    # enums
+    def c_enum(tag):
+        body = re.search(r"typedef enum %s \{(.*?)\}" % tag, hdr, flags=re.S).group(1)
+        return [int(v) for v in re.findall(r"=\s*(-?\d+)", body)]
+    def z_enum(name):
+        body = re.search(r"pub const %s = enum\([a-z_0-9]+\) \{(.*?)\};" % name, zig, flags=re.S).group(1)
+        return [int(v) for v in re.findall(r"=\s*(-?\d+)", body)]
+    assert z_enum("Mode") == c_enum("fr_mode") == [0, 1, 2, 3, 4]
+    assert z_enum("SamplePhase") == c_enum("fr_sample_phase")
+    assert z_enum("Status") == c_enum("fr_status")
+    # structs: same field names in the same order
+    def c_fields(tag):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (tag, tag), hdr, flags=re.S).group(1)
+        return [n for line in body.split(";") for n in re.findall(r"([a-z_0-9]+)\s*(?:,|$)", line.strip().split(" ", 1)[-1]) if line.strip()]
+    def z_fields(name):
+        body = re.search(r"pub const %s = extern struct \{(.*?)\};" % name, zig, flags=re.S).group(1)
+        return re.findall(r"([a-z_0-9]+):", body)
+    assert z_fields("Job") == ["glyph", "min_x", "max_y", "w", "h", "out_x", "out_y", "scale"]
+    assert set(c_fields("fr_job")) == set(z_fields("Job"))
+    assert z_fields("RasterParams") == ["mode", "samples_per_axis", "sample_phase", "reserved"]
