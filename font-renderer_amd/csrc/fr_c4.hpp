@@ -108,12 +108,13 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
     const uint32_t Hs = job.h * (uint32_t)N;
     constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
     Rec40 mine[CPT];
-    unsigned long long lm[CPT];
+    unsigned long long lm[CPT], ll[CPT];
 #pragma unroll
     for (uint32_t it = 0; it < CPT; ++it) {
         const uint32_t c = tid + it * 64u * NW;
         bool live = false;
-        lm[it] = 0ull;
+        lm[it] = 0ull; ll[it] = 0ull;
+        mine[it].fr = 0u;
         if (it > 0 && it * 64u * NW >= 2u * nseg) continue;                 // workgroup-uniform: no second candidate
         if (c < 2u * nseg) {
             Rec r;
@@ -130,8 +131,12 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
             const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
             mine[it].fr = ra | (re << 11) | (cb << 22) | (zb << 24) | (lin ? 0x80000000u : 0u);
         }
-        lm[it] = __ballot(live);
-        if (lane == 0) s_wcnt[it * NW + wave] = (uint32_t)__popcll(lm[it]);
+        // quadratic records first, linear ones (the a == 0 branch) last: the pair sequence follows the record order,
+        // so an evaluation trip is almost always all-quadratic or all-linear and takes a body without the other's work
+        const bool linr = live && (int32_t)mine[it].fr < 0;
+        lm[it] = __ballot(live && !linr);
+        ll[it] = __ballot(linr);
+        if (lane == 0) { s_wcnt[it * NW + wave] = (uint32_t)__popcll(lm[it]); s_wcnt[CPT * NW + it * NW + wave] = (uint32_t)__popcll(ll[it]); }
     }
     // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
@@ -142,23 +147,29 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
     __syncthreads();
     uint32_t rec_cnt = 0;
     {
-        uint32_t my_base[CPT];
+        uint32_t base_q[CPT], base_l[CPT], n_quad = 0;
 #pragma unroll
-        for (uint32_t it = 0; it < CPT; ++it) my_base[it] = 0;
+        for (uint32_t it = 0; it < CPT; ++it) base_q[it] = base_l[it] = 0;
 #pragma unroll
         for (uint32_t q = 0; q < CPT * NW; ++q) {
             if (q >= NW && q / NW * 64u * NW >= 2u * nseg) continue;        // (never written)
-            const uint32_t c = s_wcnt[q];
+            const uint32_t cq = s_wcnt[q], cl = s_wcnt[CPT * NW + q];
 #pragma unroll
-            for (uint32_t it = 0; it < CPT; ++it) my_base[it] += (q < it * NW + wave) ? c : 0u;
-            rec_cnt += c;
+            for (uint32_t it = 0; it < CPT; ++it) {
+                base_q[it] += (q < it * NW + wave) ? cq : 0u;
+                base_l[it] += (q < it * NW + wave) ? cl : 0u;
+            }
+            n_quad += cq;
+            rec_cnt += cq + cl;
         }
 #pragma unroll
-        for (uint32_t it = 0; it < CPT; ++it)
-            if ((lm[it] >> lane) & 1ull) {
-                const uint32_t pos = my_base[it] + (uint32_t)__popcll(lm[it] & ((1ull << lane) - 1ull));
-                if (pos < RCAP) s_rec[pos] = mine[it];                      // (the plan only sends glyphs with <= RCAP possible records)
-            }
+        for (uint32_t it = 0; it < CPT; ++it) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            uint32_t pos = RCAP;
+            if ((lm[it] >> lane) & 1ull) pos = base_q[it] + (uint32_t)__popcll(lm[it] & below);
+            if ((ll[it] >> lane) & 1ull) pos = n_quad + base_l[it] + (uint32_t)__popcll(ll[it] & below);
+            if (pos < RCAP) s_rec[pos] = mine[it];                          // (the plan only sends glyphs with <= RCAP possible records)
+        }
     }
     rec_cnt = min(rec_cnt, RCAP);
     __syncthreads();

@@ -29,6 +29,7 @@
 // windows of the row — then maps 16 counts to bytes at once.  Integer all the way: the result is the same
 // count k of inside samples per pixel, u8 = 16 k - [k > 8] = round_half_up(255 k / 16).
 #include "fr_c4.hpp"
+#include <type_traits>
 
 namespace fr {
 
@@ -230,35 +231,60 @@ void cov4_kernel(const RenderArgs A)
                         const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
                         const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
                         const float cyr = s_cy[row & 63u];
-                        // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67);
-                        // the row range [ra, re) is exactly the set of rows on which the reference accepts this
-                        // root (fr_records.hpp), so its three rejection tests (:52, :59, :64) are not repeated
-                        const float delta = cyr * r.a + r.c1 - r.c2;
-                        const float sq = sqrt_rn(delta);
-                        const float numq = r.b + sq * r.sgn, numl = cyr - r.b;
+                        // records are ordered quadratic first, linear last, so a trip is nearly always of one kind:
+                        // KIND 1 = all quadratic, 2 = all linear (no delta, no square root), 0 = mixed (both + a select)
                         const unsigned long long linm = __builtin_amdgcn_sicmp((int32_t)r.fr, 0, 40 /* ICMP_SLT */);
-                        const float num = c4_self(linm, numl, numq);
-                        const float t = div_by_int(num, r.a, r.rden);
-                        const float xx = (r.ax * t + r.bx) * t + r.p0x;
-                        const float dy = r.a * t - r.b;
-                        const uint32_t cb = (r.fr >> 22) & 3u, zb = (r.fr >> 24) & 3u;
-                        const uint32_t code = (dy > 0.0f) ? zb : cb;
-                        // J = #{ j in [0, ncol) : cx(j) <= xx }   (:54, :66) — guess, one paired read, rare walk
-                        const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                        int J = (int)gf;
-                        {
-                            const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
-                            const bool good = (c0 <= xx) & (xx < c1);
-                            if (!good & livep) {
-                                while (s_cxp[J + 1] <= xx) ++J;
-                                while (s_cxp[J] > xx) --J;
+                        const unsigned long long livem = __ballot(livep);
+                        auto body = [&](auto kind) {
+                            constexpr int KIND = decltype(kind)::value;
+                            // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67);
+                            // the row range [ra, re) is exactly the set of rows on which the reference accepts this
+                            // root (fr_records.hpp), so its three rejection tests (:52, :59, :64) are not repeated
+                            float num;
+                            if (KIND == 2) {
+                                num = cyr - r.b;
+                            } else {
+                                const float delta = cyr * r.a + r.c1 - r.c2;
+                                const float sq = sqrt_rn(delta);
+                                const float numq = r.b + sq * r.sgn;
+                                num = (KIND == 1) ? numq : c4_self(linm, cyr - r.b, numq);
                             }
-                        }
-                        if (livep & (J > 0)) {
-                            const uint32_t pos = atomicAdd(&s_cnt[row & 63u], 1u);
-                            uint16_t *rowlist = s_lists + __umul24(row & 63u, (uint32_t)C4_LSTRIDE);
-                            rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
-                        }
+                            const float t = div_by_int(num, r.a, r.rden);
+                            const float xx = (r.ax * t + r.bx) * t + r.p0x;
+                            uint32_t code;
+                            if (KIND == 2) {
+                                code = (r.fr >> 22) & 3u;                              // (:55)
+                            } else {
+                                const float dy = r.a * t - r.b;                        // (:67)
+                                if (KIND == 1) code = (dy > 0.0f) ? 0u : 2u;           // (:68)
+                                else code = (dy > 0.0f) ? ((r.fr >> 24) & 3u) : ((r.fr >> 22) & 3u);
+                            }
+                            // J = #{ j in [0, ncol) : cx(j) <= xx }   (:54, :66) — guess, one paired read, rare walk
+                            const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                            int J = (int)gf;
+                            {
+                                const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
+                                const bool good = (c0 <= xx) & (xx < c1);
+                                if (!good & livep) {
+                                    while (s_cxp[J + 1] <= xx) ++J;
+                                    while (s_cxp[J] > xx) --J;
+                                }
+                            }
+                            if (livep & (J > 0)) {
+                                const uint32_t pos = atomicAdd(&s_cnt[row & 63u], 1u);
+                                uint16_t *rowlist = s_lists + __umul24(row & 63u, (uint32_t)C4_LSTRIDE);
+                                rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
+                            }
+                        };
+#if defined(FR_C4_KINDS)
+                        // (measured: 87 vector instructions fewer per wave on C3, yet 2 % slower — 58 more branches; off)
+                        if ((linm & livem) == 0ull) body(std::integral_constant<int, 1>{});
+                        else if ((~linm & livem) == 0ull) body(std::integral_constant<int, 2>{});
+                        else body(std::integral_constant<int, 0>{});
+#else
+                        (void)livem;
+                        body(std::integral_constant<int, 0>{});
+#endif
                     }
                     k_cur = max(s_next, carry);
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
