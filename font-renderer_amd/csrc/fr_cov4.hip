@@ -71,6 +71,9 @@ __device__ __forceinline__ void c4_packed_sort(uint32_t (&d)[16])
             if (!(j & k)) c4_pce(d[j], d[j + k]);
 }
 
+#ifdef FR_C4_STATS
+__device__ unsigned long long g_c4_stats[16];
+#endif
 // LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
 template <int WLOG, int RPL>
 struct C4Lds {
@@ -226,9 +229,14 @@ void cov4_kernel(const RenderArgs A)
                         const bool livep = p < npairs;
                         // (a lane past the end decodes the last record and a row that may lie outside the band:
                         // it computes like the others and is kept from the table walk and the append)
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 7
+                        const uint32_t row = (p + (k1 & 1u)) & 63u;                                 // timing-only: no dependent decode loads
+                        const uint32_t raddr = L::CX + ((lane & 3u) + (A.n_jobs == 0xffffffffu ? k1 : 0u)) * (uint32_t)sizeof(Rec40);
+#else
                         const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u]);
                         // (one 24-bit multiply-add for the record's LDS address, small offsets for its five 8-byte reads)
                         const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
+#endif
                         const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
                         const float cyr = s_cy[row & 63u];
                         // records are ordered quadratic first, linear last, so a trip is nearly always of one kind:
@@ -265,7 +273,7 @@ void cov4_kernel(const RenderArgs A)
                             {
                                 const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
                                 const bool good = (c0 <= xx) & (xx < c1);
-                                if (!good & livep) {
+                                if (__builtin_expect(!good & livep, 0)) {
                                     while (s_cxp[J + 1] <= xx) ++J;
                                     while (s_cxp[J] > xx) --J;
                                 }
@@ -337,6 +345,24 @@ void cov4_kernel(const RenderArgs A)
             maxcnt = __ballot(cnt > 4u) ? 8u : 4u;
         }
         c4_wave_lds_sync();                        // the list region becomes E below
+#ifdef FR_C4_STATS
+        // diagnostic build only (make variant NAME=c4stats DEFS=-DFR_C4_STATS): per wave band — sort tier, crossings, over-full rows
+        if (lane == 0) {
+            atomicAdd(&g_c4_stats[0], 1ull);                                                   // wave bands with crossings
+            atomicAdd(&g_c4_stats[Hcur == 4u ? 1 : (Hcur == 8u ? 2 : 3)], 1ull);               // 8- / 16- / 32-slot sort
+            atomicAdd(&g_c4_stats[4], (unsigned long long)__popcll(ovf_rows));                 // over-full sample rows
+        }
+        {
+            const uint32_t csum = c4_wave_incl_add(cnt);
+            if (lane == 63) atomicAdd(&g_c4_stats[5], (unsigned long long)csum);               // crossings kept (J > 0)
+            const unsigned long long g8 = __ballot(cnt > 8u), g16 = __ballot(cnt > 16u), g32 = __ballot(cnt > 32u);
+            if (lane == 0) {
+                atomicAdd(&g_c4_stats[6], (unsigned long long)__popcll(g8));                   // rows with > 8 / > 16 / > 32 crossings
+                atomicAdd(&g_c4_stats[7], (unsigned long long)__popcll(g16));
+                atomicAdd(&g_c4_stats[8], (unsigned long long)__popcll(g32));
+            }
+        }
+#endif
 
 #if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 6
         if (A.n_jobs != 0xffffffffu) { if (d[0] + d[3] + d[7] + d[15] + Hcur + maxcnt == 0x12345u) s_cnt[0] = 1u; continue; }   // timing-only: up to the sort
@@ -395,7 +421,7 @@ void cov4_kernel(const RenderArgs A)
             // the row's constant: 4 [w(0) != 0], into byte 0 of the pixel row
             if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), 4u);
         }
-        if (ovf_rows) {
+        if (__builtin_expect(ovf_rows != 0ull, 0)) {
             // ---- over-full sample rows (more than CAP crossings): the direct sum.  Every record of mine whose row
             // range holds the row is evaluated once more and adds its step to a row of 16-bit winding DIFFERENCES
             // in LDS (w(j) = sum over i >= j of d[i]: d[J - 1] += step; the 2 KB next to E, free since the lists
@@ -512,6 +538,17 @@ size_t cov4_lds_bytes(int wlog, int rpl)
     if (rpl == 4) return wlog == 4 ? C4Lds<4, 4>::TOTAL : C4Lds<3, 4>::TOTAL;
     return wlog == 4 ? C4Lds<4, 8>::TOTAL : C4Lds<3, 8>::TOTAL;
 }
+#ifdef FR_C4_STATS
+extern "C" int fr_debug_read_c4_stats(unsigned long long *out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_c4_stats), sizeof(g_c4_stats));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_c4_stats), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -2;
+}
+#endif
 uint32_t cov4_wg_waves() { return C4_WAVES; }
 uint32_t cov4_max_segments() { return 256u; }
 

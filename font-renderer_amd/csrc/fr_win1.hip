@@ -183,7 +183,7 @@ void win1_kernel(const RenderArgs A)
                         {
                             const float c0 = s_cxp[J], c1 = s_cxp[J + 1];
                             const bool good = (c0 <= xx) & (xx < c1);
-                            if (!good & livep) {
+                            if (__builtin_expect(!good & livep, 0)) {
                                 while (s_cxp[J + 1] <= xx) ++J;
                                 while (s_cxp[J] > xx) --J;
                             }
