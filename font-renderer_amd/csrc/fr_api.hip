@@ -420,9 +420,9 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     {
         // (cov4_kernel: 16 samples per pixel; win1_kernel: the one-sample modes, cells up to 1024 pixels tall)
         const bool one = params->mode == FR_WINDING_I16 || params->mode == FR_GRAY_DEBUG || params->mode == FR_MASK_NONZERO ||
-                         (params->mode == FR_COVERAGE_U8 && n == 1u);
+                         (params->mode == FR_COVERAGE_U8 && n == 1u) || params->mode == FR_SDF_U8;   // (SDF: its sign pass)
         const bool mode_ok = ctx->cov4 && (sw == 128u || sw == 256u) && ((params->mode == FR_COVERAGE_U8 && n == 4u) || one);
-        const uint32_t max_h_fast = one ? 1024u : 256u;
+        const uint32_t max_h_fast = one ? 2048u : 512u;                  // (sample rows <= 2048: 12-bit row fields)
         std::vector<uint32_t> mid, slow;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             const fr_job &jb = jobs[j];
@@ -567,14 +567,16 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.job_seg = plan->d_job_seg + 2u * (size_t)n_fast;
         a.n_jobs = n_gen; a.bands = plan->gen_bands; a.strips = plan->gen_strips; a.uniform = plan->uniform ? 1u : 0u;
         split_bands(fr::render_wg_waves(), n_gen, plan->gen_bands, plan->gen_strips);
-        if (sdf) {
-            // sign first: the render kernel's 1-sample coverage (255 where the reference's winding is non-zero,
-            // same sample points) lands in the output; the distance kernel reads it and overwrites it
-            HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
-            HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, (int)plan->ctx->sdf_cull, plan->ctx->stream));
-            return FR_OK;
-        }
-        HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
+        // SDF, sign first: the 1-sample coverage (255 where the reference's winding is non-zero, same sample points)
+        // lands in the output; the distance kernel reads it and overwrites it
+        if (sdf) HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
+        else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
+    }
+    if (sdf) {
+        a.jobs = plan->d_jobs;
+        a.job_seg = plan->d_job_seg;
+        a.n_jobs = plan->n_jobs;
+        HIP_TRY(fr::launch_sdf(a, plan->gs->d_pts, plan->gs->d_seg_p0, plan->max_w, plan->max_h, (int)plan->ctx->sdf_cull, plan->ctx->stream));
     }
     return FR_OK;
 }

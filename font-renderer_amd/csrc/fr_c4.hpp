@@ -42,7 +42,7 @@ struct __attribute__((aligned(8))) Rec40 {
     float ax, bx, p0x;   // (:53 / :65)
     float rden;     // RN(1 / a)
     float sgn;      // +1 for the t+ root, -1 for t-  (sqrt * +-1 is exact: B - sqrt == B + (-sqrt))
-    uint32_t fr;    // ra | re << 11 | cb << 22 | zb << 24 | linear << 31: sample rows [ra, re) accept the root;
+    uint32_t fr;    // ra | re << 12 | cb << 24 | zb << 26 | linear << 31 (ra, re <= 2048): sample rows [ra, re) accept the root;
                     // the crossing's step code is (dy > 0) ? zb : cb   (2: +1, 0: -1; :55, :68)
 };
 
@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
             mine[it].ax = r.ax; mine[it].bx = r.bx; mine[it].p0x = r.p0x; mine[it].rden = r.rden;
             mine[it].sgn = r.sqsign ? -1.0f : 1.0f;
             const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
-            mine[it].fr = ra | (re << 11) | (cb << 22) | (zb << 24) | (lin ? 0x80000000u : 0u);
+            mine[it].fr = ra | (re << 12) | (cb << 24) | (zb << 26) | (lin ? 0x80000000u : 0u);
         }
         // quadratic records first, linear ones (the a == 0 branch) last: the pair sequence follows the record order,
         // so an evaluation trip is almost always all-quadratic or all-linear and takes a body without the other's work

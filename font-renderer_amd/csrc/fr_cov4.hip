@@ -145,8 +145,8 @@ void cov4_kernel(const RenderArgs A)
         const uint32_t k = per * lane + (uint32_t)i;
         const bool have = k < rec_cnt && (!few || i < 2);
         const uint32_t f = s_rec[have ? k : 0u].fr;
-        rra[i] = have ? (f & 0x7ffu) : 1u;
-        rre[i] = have ? ((f >> 11) & 0x7ffu) : 0u;
+        rra[i] = have ? (f & 0xfffu) : 1u;
+        rre[i] = have ? ((f >> 12) & 0xfffu) : 0u;
     }
 
     uint16_t *s_lists = reinterpret_cast<uint16_t *>(wregion);
@@ -261,11 +261,11 @@ void cov4_kernel(const RenderArgs A)
                             const float xx = (r.ax * t + r.bx) * t + r.p0x;
                             uint32_t code;
                             if (KIND == 2) {
-                                code = (r.fr >> 22) & 3u;                              // (:55)
+                                code = (r.fr >> 24) & 3u;                              // (:55)
                             } else {
                                 const float dy = r.a * t - r.b;                        // (:67)
                                 if (KIND == 1) code = (dy > 0.0f) ? 0u : 2u;           // (:68)
-                                else code = (dy > 0.0f) ? ((r.fr >> 24) & 3u) : ((r.fr >> 22) & 3u);
+                                else code = (dy > 0.0f) ? ((r.fr >> 26) & 3u) : ((r.fr >> 24) & 3u);
                             }
                             // J = #{ j in [0, ncol) : cx(j) <= xx }   (:54, :66) — guess, one paired read, rare walk
                             const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
@@ -448,7 +448,7 @@ void cov4_kernel(const RenderArgs A)
                         const float t = div_by_int(num, rk.a, rk.rden);
                         const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
                         const float dy = rk.a * t - rk.b;
-                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
+                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
                         int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
                         while (s_cxp[J + 1] <= xx) ++J;
                         while (s_cxp[J] > xx) --J;

@@ -90,8 +90,8 @@ void win1_kernel(const RenderArgs A)
         const uint32_t k = per * lane + (uint32_t)i;
         const bool have = k < rec_cnt && (!few || i < 2);
         const uint32_t f = s_rec[have ? k : 0u].fr;
-        rra[i] = have ? (f & 0x7ffu) : 1u;
-        rre[i] = have ? ((f >> 11) & 0x7ffu) : 0u;
+        rra[i] = have ? (f & 0xfffu) : 1u;
+        rre[i] = have ? ((f >> 12) & 0xfffu) : 0u;
     }
 
     unsigned char *s_E = wregion;
@@ -175,7 +175,7 @@ void win1_kernel(const RenderArgs A)
                         const float t = div_by_int(num, r.a, r.rden);
                         const float xx = (r.ax * t + r.bx) * t + r.p0x;
                         const float dy = r.a * t - r.b;
-                        const uint32_t cb = (r.fr >> 22) & 3u, zb = (r.fr >> 24) & 3u;
+                        const uint32_t cb = (r.fr >> 24) & 3u, zb = (r.fr >> 26) & 3u;
                         const uint32_t code = (dy > 0.0f) ? zb : cb;
                         // J = #{ x in [0, NCOL) : cx(x) <= xx }   (:54, :66)
                         const float gf = __builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
@@ -243,7 +243,7 @@ void win1_kernel(const RenderArgs A)
                         const float t = div_by_int(num, rk.a, rk.rden);
                         const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
                         const float dy = rk.a * t - rk.b;
-                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 24) & 3u) : ((rk.fr >> 22) & 3u)) - 1u;
+                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;
                         int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
                         while (s_cxp[J + 1] <= xx) ++J;
                         while (s_cxp[J] > xx) --J;

@@ -235,6 +235,28 @@ def test_win1_kernel_matches_the_oracle(ctx, oracle, mode, omode):
     assert np.array_equal(got, ref)
 
 
+def test_tall_cells_take_the_fast_kernels(ctx, oracle):
+    """cells up to 512 pixels tall (16 samples) / 2048 (one sample) stay on cov4_kernel / win1_kernel: a 256 x 512
+    and a 512 x 512 cell against the oracle, and a 128 x 1040 gray cell"""
+    gs = synth_glyphset(2, 96, first_index=4040)
+    rows = [(0, int(np.floor(gs.boxes[0][0] * 0.2)), int(np.ceil(gs.boxes[0][3] * 0.2)) + 40, 256, 512, 0, 0, np.float32(0.2)),
+            (1, int(np.floor(gs.boxes[1][0] * 0.25)) - 8, int(np.ceil(gs.boxes[1][3] * 0.25)) + 8, 512, 512, 256, 0, np.float32(0.25))]
+    jobs = rg.make_jobs(rows)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+    assert plan.stats() == {"jobs_cov4": 2, "jobs_general": 0}
+    plan.close()
+    got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, (512, 768), 4, True, threads=16, dgs=dgs)
+    assert np.array_equal(got, ref)
+    tall = rg.make_jobs([(0, int(np.floor(gs.boxes[0][0] * 0.06)), int(np.ceil(gs.boxes[0][3] * 0.5)) + 8, 128, 1040, 0, 0, np.float32(0.5))])
+    plan = fr.Plan(dgs, tall, fr.FR_GRAY_DEBUG, 1, fr.FR_SAMPLE_CORNER)
+    assert plan.stats()["jobs_cov4"] == 1
+    plan.close()
+    got, ref = _batch_both(ctx, oracle, gs, tall, fr.FR_GRAY_DEBUG, (1040, 128), 1, False, threads=16, dgs=dgs)
+    dgs.close()
+    assert np.array_equal(got, ref) and (ref != 100).any()
+
+
 def test_cov4_equals_general_kernel_on_2048_cells(ctx):
     """2 048 glyphs x 256^2 (a tenth of configs[2]) through cov4_kernel and through the general kernel:
     identical bytes (the general kernel is the one the oracle checks at small sizes)"""
