@@ -274,12 +274,12 @@ def main():
             buf = np.zeros(im.width * im.height, np.uint8)
             lib = L.load_library()
             call = lambda: lib.fr_render_glyph(ctx._h, L.ptr(pts), L.ptr(cs), len(cs) - 1, L.ptr(box), info.units_per_em, 64, fr.FR_GRAY_DEBUG, L.ptr(buf))
-            for _ in range(50):
+            for _ in range(300):
                 call()
             tc = time.perf_counter()
-            for _ in range(500):
+            for _ in range(1000):
                 rc1 = call()
-            us = (time.perf_counter() - tc) / 500 * 1e6
+            us = (time.perf_counter() - tc) / 1000 * 1e6
             assert rc1 == 0 and np.array_equal(buf, im.data)
             c1 = {"config": "configs[0]: STIX 'A', font_size 64 -> 47x45 gray; one fr_render_glyph call (upload, render, download, sync)",
                   "us_per_call": round(us, 1), "size": [im.width, im.height]}

@@ -104,7 +104,8 @@ int fr_ctx_sync(fr_ctx *ctx);
  * exact direct-sum fallback: rounded up to 8, 16 or 32; default 32), "strip_px" (column
  * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip),
  * "cov4" (0: every job takes the general kernel), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
- * every pixel — the culls are exact, this is how the tests show it), "min_wgs", "fuse_prepare", "lds_pad" */
+ * every pixel — the culls are exact, this is how the tests show it), "zero_copy" (1: fr_render_glyph renders small
+ * glyphs straight from / into pinned host memory; measured no faster, off by default), "min_wgs", "fuse_prepare", "lds_pad"                                    */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 
 /* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------
