@@ -57,6 +57,16 @@ struct Winding {                                      // Image.zig:85-130
         if (val > 0) { rgb[0] = sub; rgb[1] = sub; rgb[2] = color; } else { rgb[0] = color; rgb[1] = sub; rgb[2] = sub; }
     }
 };
+struct RGB {                                          // Image.zig:132-170
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> data;                        // row-major RGB triples
+    static RGB init(uint32_t w, uint32_t h) { RGB g; g.width = w; g.height = h; g.data.assign((size_t)w * h * 3, 0); return g; }
+    void getRGBLinear(size_t index, uint8_t rgb[3]) const { rgb[0] = data[3 * index]; rgb[1] = data[3 * index + 1]; rgb[2] = data[3 * index + 2]; }
+};
+struct GlyphDebug {                                   // Image.zig:173-241
+    RGB rgb;
+    uint8_t winding_scale = 50, overflow_color = 150;
+};
 }  // namespace Image
 
 class Context {
@@ -120,6 +130,48 @@ inline int16_t windingInGlyph(Context &ctx, const Glyph &glyph, Point p)
     int16_t out = 0;
     check(fr_winding_in_glyph(ctx.get(), f.pts.data(), f.cstart.data(), f.n_contours(), q, 1, &out));
     return out;
+}
+
+// Image.zig:220 — Image.GlyphDebug.render(glyph, winding_scale): the exact-integer lattice coloured, points marked
+inline Image::GlyphDebug glyphDebugRender(Context &ctx, const Glyph &glyph, uint8_t winding_scale)
+{
+    const int16_t box[4] = {glyph.box.x_min, glyph.box.y_min, glyph.box.x_max, glyph.box.y_max};
+    Image::GlyphDebug im;
+    im.winding_scale = winding_scale;
+    im.rgb = Image::RGB::init((uint32_t)(box[2] - box[0] + 3), (uint32_t)(box[3] - box[1] + 3));     // :183
+    Flat f(glyph);
+    check(fr_glyph_debug_render(ctx.get(), f.pts.data(), f.cstart.data(), f.n_contours(), box, winding_scale, im.rgb.data.data()));
+    return im;
+}
+
+// a batch of glyphs -> one atlas (build-defined cell grid, fr_atlas_layout) of n x n-sample coverage
+inline Image::Gray renderAtlas(Context &ctx, const std::vector<Glyph> &glyphs, FontInformation font_info, uint16_t font_size,
+                               uint32_t cell, uint32_t cols, int samples_per_axis)
+{
+    std::vector<int16_t> pts, boxes;
+    std::vector<uint32_t> cstart{0}, gstart{0};
+    for (const Glyph &g : glyphs) {
+        for (const Contour &c : g.contours) {
+            for (const Point &p : c.points) { pts.push_back(p.x); pts.push_back(p.y); }
+            cstart.push_back((uint32_t)(pts.size() / 2));
+        }
+        gstart.push_back((uint32_t)cstart.size() - 1);
+        boxes.insert(boxes.end(), {g.box.x_min, g.box.y_min, g.box.x_max, g.box.y_max});
+    }
+    if (pts.empty()) pts.assign(2, 0);
+    const uint32_t n = (uint32_t)glyphs.size();
+    std::vector<fr_job> jobs(n ? n : 1);
+    const uint16_t upm = font_info.units_per_em;
+    check(fr_atlas_layout(boxes.data(), n, 0, &upm, 1, font_size, cell, cols, 0, jobs.data(), nullptr, nullptr));
+    fr_glyphset *gs = nullptr;
+    check(fr_glyphset_create(ctx.get(), pts.data(), cstart.data(), (uint32_t)cstart.size() - 1, gstart.data(), n, &gs));
+    const uint32_t rows = (n + cols - 1) / cols;
+    Image::Gray im = Image::Gray::init(cols * cell, rows * cell);
+    fr_raster_params prm{FR_COVERAGE_U8, samples_per_axis, FR_SAMPLE_CENTER, 0};
+    const int rc = fr_render_batch(ctx.get(), gs, jobs.data(), n, &prm, im.data.data(), (size_t)cols * cell, (size_t)rows * cell);
+    fr_glyphset_destroy(gs);
+    check(rc);
+    return im;
 }
 
 }  // namespace fr_host

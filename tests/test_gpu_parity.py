@@ -702,7 +702,7 @@ def test_cpp_host_mirror(ctx, ascii_set, tmp_path):
     env = dict(os.environ, FR_HIP_RUNTIME="system")
     out = subprocess.run([exe, str(tmp_path / "pts.bin"), str(tmp_path / "cs.bin")], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stderr
-    w, h, hm2, hm1, h0, h1, fnv, wi = out.stdout.split()
+    w, h, hm2, hm1, h0, h1, fnv, wi, fnv_dbg, fnv_atlas = out.stdout.split()
     assert (int(w), int(h), int(hm2), int(hm1), int(h0), int(h1)) == (47, 45, 1, 28, 1641, 445)
     assert int(wi) == 0
     gray = fr.renderGlyph(ascii_set.glyph(i), fr.FontInformation(1000), 64, ctx=ctx).data
@@ -710,6 +710,20 @@ def test_cpp_host_mirror(ctx, ascii_set, tmp_path):
     for b in gray.tolist():
         hh = ((hh ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert int(fnv, 16) == hh
+
+    def fnv1a(buf):
+        x = 1469598103934665603
+        for b in buf.tolist():
+            x = ((x ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return x
+    g = ascii_set.glyph(i)
+    assert int(fnv_dbg, 16) == fnv1a(fr.GlyphDebug.render(g, 50, ctx=ctx).rgb.data.reshape(-1))
+    gs2 = GlyphSet([g, g])
+    atlas = np.zeros((128, 256), np.uint8)
+    dgs = fr.DeviceGlyphSet(ctx, gs2)
+    rg.render_batch(dgs, cell_jobs(gs2, 128, 100, 1000, 2), fr.FR_COVERAGE_U8, atlas, 4, fr.FR_SAMPLE_CENTER)
+    dgs.close()
+    assert int(fnv_atlas, 16) == fnv1a(atlas.reshape(-1))
 
 
 def test_division_shortcut_is_exact_exhaustively(ctx):
