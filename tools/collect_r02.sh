@@ -24,7 +24,7 @@ for w in c3_cjk21k_256px_s128_16spp c3_cjk21k_256px_s256_16spp c3_strokes21k_256
   cp $out/kt_$w/kt_kernel_stats.csv $out/${w}_kernel_stats.csv 2>/dev/null
   echo "kt $w done"
 done
-for w in c3_cjk21k_256px_s128_16spp c5_sdf_shard_512px_s64 c3_cjk21k_256px_s128_winding_i16; do
+for w in c3_cjk21k_256px_s128_16spp c5_sdf_shard_512px_s64 c3_cjk21k_256px_s128_winding_i16 c3_cjk21k_256px_s128_gray_debug; do
   for c in WRITE_SIZE FETCH_SIZE; do
     rocprofv3 --output-format csv --pmc $c -d $out/pmc_${w}_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
   done
@@ -41,7 +41,7 @@ for d in sorted(glob.glob("$out/pmc_*")):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,cs in acc.items():
-        if not any(t in k for t in ("cov4", "render_kernel", "sdf_kernel", "prepare")): continue
+        if not any(t in k for t in ("cov4", "win1", "render_kernel", "sdf_kernel", "prepare")): continue
         for c,v in sorted(cs.items()): print(f"{os.path.basename(d):55s} {k:70s} {c:22s} {sum(v)/len(v):.6g}")
 PY
 cat $out/pmc_summary.txt
