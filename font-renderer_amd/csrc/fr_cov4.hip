@@ -450,8 +450,11 @@ void cov4_kernel(const RenderArgs A)
                         const float dy = rk.a * t - rk.b;
                         const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
                         int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                        while (s_cxp[J + 1] <= xx) ++J;
-                        while (s_cxp[J] > xx) --J;
+                        const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
+                        if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
+                            while (s_cxp[J + 1] <= xx) ++J;
+                            while (s_cxp[J] > xx) --J;
+                        }
                         if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
                     }
                 }

@@ -13,29 +13,61 @@
 //                coverage left in the output (255 / 0) right before this kernel
 //   encoding   : u8 = clamp(floor(128 + 16*d + 0.5), 0, 255)   (8 pixels of range either side)
 //
-// Shape: one workgroup per 16x16-pixel tile of a cell, one lane per pixel; the glyph's control
-// points are staged through LDS as f32 (256 segments at a time) and read back as broadcasts.
-// The encoding saturates 8 pixels from the outline, so a segment whose control-point box (the curve
-// lies inside it) is farther than that from the whole tile cannot change any of the tile's bytes: it
-// is dropped while staging (LDS counter compaction; the minimum does not depend on the order).  The
-// distance the kernel computes is the distance to SOME point of the curve, hence >= the box distance:
-// every dropped segment would have produced a value past the clamp.
+// Shape: one WAVE (a 64-lane workgroup, no barriers) per 32x32-pixel region of a cell, taken as 16 quads of
+// 8x8 pixels, one lane per pixel.  The encoding saturates 8 pixels from the outline, so a segment whose
+// bounding box is farther than that from a set of sample points cannot change any of their bytes.  The box
+// is ORIENTED along the chord: B(t) = chord(t) + 2t(1-t) v with v = p1 - (p0 + p2)/2 and 2t(1-t) in [0, 1/2],
+// so in the frame (tau, n) of the chord the curve stays inside [min(0, va/2), L + max(0, va/2)] x
+// [min(0, vb/2), max(0, vb/2)] — for a long diagonal or gently bent segment a far thinner set than the
+// axis-aligned box of its control points.  It is used three times, each time exactly:
+//   region : the wave reads the glyph's segments 64 at a time (one per lane, 12 bytes) and keeps those within
+//            reach of the region's sample box — ballot + lane-prefix compaction into an LDS list that also
+//            holds what does not depend on the sample: A, the second difference and the probe points B(k/8);
+//   quad   : lane k tests list entry k against the quad's sample box; the ballot is the quad's candidate set.
+//            A quad without candidates keeps the byte the sign pass left (255 / 0 — what the encoding gives
+//            for "farther than 8 pixels"), so nothing is read or written for it;
+//   pixel  : per candidate, the pixel's own box distance against the reach and against the best so far.
+// The distance the kernel computes is the distance to SOME point of the curve, hence >= the box distance: every
+// skipped segment would have produced a value past the clamp or not below the minimum, so the minimum over the
+// segments that are evaluated is the minimum over all of them, whatever the order (option "sdf_cull" = 0 skips
+// nothing; tests compare the two).  Glyphs of more than 64 segments: the per-pixel minima of a region wait in
+// LDS between blocks.
 #include "fr_device.hpp"
 
 namespace fr {
 
-__device__ __forceinline__ float seg_dist2(float p0x, float p0y, float p1x, float p1y, float p2x, float p2y,
-                                           float qx, float qy)
+constexpr uint32_t SDF_REGION = 32u;          // pixels per side of a wave's region: 4 x 4 quads of 8 x 8 pixels
+constexpr uint32_t SDF_BLOCK = 64u;           // segments read per block, one per lane (48, for 16 waves per CU instead of 13, was no faster: the kernel is VALU-bound)
+constexpr uint32_t SDF_ENTRY = 28u;           // floats per staged segment (7 x 16 bytes):
+// [0..3] p0x p0y Ax Ay   [4..7] tau_x tau_y a_lo a_hi   [8..11] b_lo b_hi Dx Dy (second difference)
+// [12..19] Bx(k/8), k = 1..8   [20..27] By(k/8)
+
+// |B(t) - q|^2 minimised over t in [0,1] as the header defines it; `e` is the staged entry.  The probe points
+// B(k/8) = (p0 + (2t) A) + (t t) D are the same roundings as the header's expression tree — 2t and t t are exact
+// for t = k/8 — only hoisted out of the pixel.
+__device__ __forceinline__ float seg_dist2(const float *e, float qx, float qy)
 {
-    const float ax = p1x - p0x, ay = p1y - p0y;                         // A
-    const float bx = p0x - 2.0f * p1x + p2x, by = p0y - 2.0f * p1y + p2y;   // second difference
+    const float4 pa = *reinterpret_cast<const float4 *>(e);
+    const float2 dd = *reinterpret_cast<const float2 *>(e + 10);
+    const float p0x = pa.x, p0y = pa.y, ax = pa.z, ay = pa.w, bx = dd.x, by = dd.y;
     float best = 3.402823466e+38f, bt = 0.0f;
-    for (int k = 0; k <= 8; ++k) {
-        const float t = (float)k * 0.125f;
-        const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
-        const float y = p0y + 2.0f * t * ay + t * t * by - qy;
+    {
+        const float x = p0x - qx, y = p0y - qy;                          // k = 0: B(0) = p0
         const float d2 = x * x + y * y;
-        if (d2 < best) { best = d2; bt = t; }
+        if (d2 < best) { best = d2; bt = 0.0f; }
+    }
+    float px[8], py[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float4 vx = *reinterpret_cast<const float4 *>(e + 12 + 4 * k), vy = *reinterpret_cast<const float4 *>(e + 20 + 4 * k);
+        px[4 * k] = vx.x; px[4 * k + 1] = vx.y; px[4 * k + 2] = vx.z; px[4 * k + 3] = vx.w;
+        py[4 * k] = vy.x; py[4 * k + 1] = vy.y; py[4 * k + 2] = vy.z; py[4 * k + 3] = vy.w;
+    }
+#pragma unroll
+    for (int k = 1; k <= 8; ++k) {
+        const float x = px[k - 1] - qx, y = py[k - 1] - qy;
+        const float d2 = x * x + y * y;
+        if (d2 < best) { best = d2; bt = (float)k * 0.125f; }
     }
     const float lo = fmaxf(bt - 0.125f, 0.0f), hi = fminf(bt + 0.125f, 1.0f);
     float t = bt;
@@ -57,101 +89,197 @@ __device__ __forceinline__ float seg_dist2(float p0x, float p0y, float p1x, floa
     return best;
 }
 
-__global__ __launch_bounds__(256) void sdf_kernel(const Job *__restrict__ jobs, const int16_t *__restrict__ pts,
-                                                  const uint32_t *__restrict__ seg_p0,
-                                                  const uint32_t *__restrict__ glyph_seg_start,
-                                                  const uint32_t *__restrict__ glyph_rec_count,
-                                                  const Rec *__restrict__ recs, uint8_t *__restrict__ out,
-                                                  uint64_t out_stride, uint32_t tiles_x, uint32_t tiles_y,
-                                                  int phase_center, int cull)
+// The oriented box of a segment: unit chord direction tau (n = (-tau_y, tau_x)), the box [a_lo, a_hi] x [b_lo, b_hi] in
+// that frame about p0.  A degenerate chord (p0 == p2) takes the x axis.  The frame is only as good as float: |tau|
+// is 1 within a few 2^-24 and the box edges carry a few roundings of magnitudes <= 2^17 — all far inside the
+// `slack` every user of obb_gap2 subtracts.
+struct Obb { float tx, ty, alo, ahi, blo, bhi; };
+
+__device__ __forceinline__ Obb make_obb(const float *c)
 {
-    __shared__ float s_seg[256][10];            // p0, p1, p2 and the control-point box (x0, x1, y0, y1)
-    __shared__ uint32_t s_n;
-    uint32_t bid = blockIdx.x;
-    const uint32_t tx = bid % tiles_x; bid /= tiles_x;
-    const uint32_t ty = bid % tiles_y;
-    const uint32_t jidx = bid / tiles_y;
-    const Job job = jobs[jidx];
-    if (tx * 16u >= job.w || ty * 16u >= job.h) return;
-    // each wave takes an 8x8 quarter of the tile (not a 16x4 strip): the per-pixel cull below only saves
-    // work when all 64 lanes agree, and a compact square agrees more often
-    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-    const uint32_t x = tx * 16u + (wv & 1u) * 8u + (ln & 7u), y = ty * 16u + (wv >> 1) * 8u + (ln >> 3);
-    const bool valid = x < job.w && y < job.h;
-    const float off = phase_center ? 0.5f : 0.0f;
-    const float qx = ((float)(job.min_x + (int32_t)x) + off) / job.scale;       // render_glyph.zig:26
-    const float qy = ((float)(job.max_y - (int32_t)y) - off) / job.scale;       // :27
-    const uint32_t s0 = glyph_seg_start[job.glyph], s1 = glyph_seg_start[job.glyph + 1];
-    // the tile's sample points span [tqx0, tqx1] x [tqy0, tqy1] (font units; the maps are monotone)
-    const float tqx0 = ((float)(job.min_x + (int32_t)(tx * 16u)) + off) / job.scale;
-    const float tqx1 = ((float)(job.min_x + (int32_t)(tx * 16u + 15u)) + off) / job.scale;
-    const float tqy1 = ((float)(job.max_y - (int32_t)(ty * 16u)) - off) / job.scale;
-    const float tqy0 = ((float)(job.max_y - (int32_t)(ty * 16u + 15u)) - off) / job.scale;
-    // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding.
-    // cull == 0 (ctx option "sdf_cull", tests): no segment is ever dropped or skipped
-    const float reach = cull ? 8.0f / job.scale * 1.02f + 1.0f : 3.0e+37f;
-    // A computed curve point B(t) - q can leave the control-point box by a few roundings of its three-term sum
-    // (each <= half an ulp of a magnitude <= 2^18 for i16 points: < 2^-6 font units, far less relative to a
-    // distant sample).  The boxes the culls look at are therefore grown by `slack`, so that "the computed
-    // distance is >= the box distance" holds for the ROUNDED distance too and a skipped segment can never have
-    // produced a smaller value — whatever order the segments were staged in.
-    const float slack = 0.25f + 1.0e-6f * (fabsf(qx) + fabsf(qy));
-    float best = 3.402823466e+38f;
-    for (uint32_t base = s0; base < s1; base += 256u) {
-        if (threadIdx.x == 0) s_n = 0u;
-        __syncthreads();
-        const uint32_t s = base + threadIdx.x;
-        if (s < s1) {
-            const int16_t *p = pts + 2u * (size_t)seg_p0[s];
-            float c[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) c[k] = (float)p[k];
-            const float hx0 = fminf(fminf(c[0], c[2]), c[4]), hx1 = fmaxf(fmaxf(c[0], c[2]), c[4]);
-            const float hy0 = fminf(fminf(c[1], c[3]), c[5]), hy1 = fmaxf(fmaxf(c[1], c[3]), c[5]);
-            const float gx = fmaxf(fmaxf(hx0 - tqx1, tqx0 - hx1), 0.0f), gy = fmaxf(fmaxf(hy0 - tqy1, tqy0 - hy1), 0.0f);
-            if (!cull || gx * gx + gy * gy <= reach * reach) {
-                const uint32_t slot = atomicAdd(&s_n, 1u);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s_seg[slot][k] = c[k];
-                s_seg[slot][6] = hx0; s_seg[slot][7] = hx1; s_seg[slot][8] = hy0; s_seg[slot][9] = hy1;
-            }
-        }
-        __syncthreads();
-        const uint32_t n = s_n;
-        if (valid)
-            for (uint32_t k = 0; k < n; ++k) {
-                // per pixel the same argument: the computed distance is >= the distance to the segment's box,
-                // so a box no nearer than the best so far (or than the saturation reach) changes nothing
-                const float gx = fmaxf(fmaxf(s_seg[k][6] - qx, qx - s_seg[k][7]) - slack, 0.0f);
-                const float gy = fmaxf(fmaxf(s_seg[k][8] - qy, qy - s_seg[k][9]) - slack, 0.0f);
-                const float g2 = gx * gx + gy * gy;
-                if (cull && (g2 >= best || g2 > reach * reach)) continue;
-                const float d2 = seg_dist2(s_seg[k][0], s_seg[k][1], s_seg[k][2], s_seg[k][3], s_seg[k][4], s_seg[k][5], qx, qy);
-                if (d2 < best) best = d2;
-            }
-        __syncthreads();
-    }
-    if (!valid) return;
-    uint8_t *px = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
-    const bool inside = *px != 0;              // render_kernel<COVERAGE_U8, 1>: winding != 0 at this sample
-    float d = (s1 > s0) ? __builtin_sqrtf(best) * job.scale : 3.402823466e+38f;
-    if (!inside) d = -d;
-    float v = 16.0f * d + 128.0f;
-    v = floorf(v + 0.5f);
-    v = fminf(fmaxf(v, 0.0f), 255.0f);
-    *px = (uint8_t)v;
+    const float ux = c[4] - c[0], uy = c[5] - c[1];
+    const float len = __builtin_sqrtf(ux * ux + uy * uy);
+    Obb o;
+    o.tx = len > 0.0f ? ux / len : 1.0f;
+    o.ty = len > 0.0f ? uy / len : 0.0f;
+    const float vx = c[2] - 0.5f * (c[0] + c[4]), vy = c[3] - 0.5f * (c[1] + c[5]);     // v = p1 - midpoint (exact for i16 points)
+    const float va = 0.5f * (vx * o.tx + vy * o.ty), vb = 0.5f * (vy * o.tx - vx * o.ty);
+    o.alo = fminf(va, 0.0f); o.ahi = len + fmaxf(va, 0.0f);
+    o.blo = fminf(vb, 0.0f); o.bhi = fmaxf(vb, 0.0f);
+    return o;
 }
 
-hipError_t launch_sdf(const RenderArgs &a, const int16_t *pts, const uint32_t *seg_p0, uint32_t max_w,
-                      uint32_t max_h, int cull, hipStream_t stream)
+// squared distance from q to the oriented box after the box has been grown by `grow` on every side (0 inside)
+__device__ __forceinline__ float obb_gap2(float p0x, float p0y, float tx, float ty, float alo, float ahi, float blo, float bhi,
+                                          float qx, float qy, float grow)
+{
+    const float wx = qx - p0x, wy = qy - p0y;
+    const float a = wx * tx + wy * ty, b = wy * tx - wx * ty;
+    const float da = fmaxf(fmaxf(alo - a, a - ahi) - grow, 0.0f), db = fmaxf(fmaxf(blo - b, b - bhi) - grow, 0.0f);
+    return da * da + db * db;
+}
+
+__global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const int16_t *__restrict__ seg_pts,
+                                                 const uint32_t *__restrict__ glyph_seg_start, uint8_t *__restrict__ out,
+                                                 uint64_t out_stride, uint32_t regions_x, uint32_t regions_y,
+                                                 int phase_center, int cull)
+{
+    __shared__ __attribute__((aligned(16))) float s_seg[SDF_BLOCK * SDF_ENTRY];
+    __shared__ float s_best[16u * 64u];         // per-pixel minima of the region between blocks of segments
+    __shared__ float s_xy[64];                  // the region's 32 sample abscissae, then its 32 sample ordinates
+    uint32_t bid = blockIdx.x;
+    const uint32_t rxi = bid % regions_x; bid /= regions_x;
+    const uint32_t ryi = bid % regions_y;
+    const Job job = jobs[bid / regions_y];
+    const uint32_t X0 = rxi * SDF_REGION, Y0 = ryi * SDF_REGION;
+    if (X0 >= job.w || Y0 >= job.h) return;
+    const uint32_t lane = threadIdx.x;
+    const float off = phase_center ? 0.5f : 0.0f;
+    const float scale = job.scale;
+    // sample coordinates exactly as renderGlyph's (render_glyph.zig:26-27): lane l < 32 holds the abscissa of the
+    // region's column l, lane 32 + l the ordinate of its row l — one division per lane for the whole region
+    const float xy = lane < 32u ? ((float)(job.min_x + (int32_t)(X0 + lane)) + off) / scale
+                                : ((float)(job.max_y - (int32_t)(Y0 + lane - 32u)) - off) / scale;
+    s_xy[lane] = xy;
+    // A set of sample points is tested as the disc about its box's centre: radius = half the diagonal, plus the
+    // pixel test's slack at its farthest corner (see there), plus a margin for the roundings of this very sum.
+    // Both maps are monotone in the pixel index, so the corners are the first and last column / row.
+    auto disc = [](float xa, float xb, float ya, float yb, float &cx, float &cy, float &rad) {
+        cx = 0.5f * (xa + xb); cy = 0.5f * (ya + yb);
+        const float hx = 0.5f * (xb - xa), hy = 0.5f * (yb - ya);
+        rad = __builtin_sqrtf(hx * hx + hy * hy) * 1.001f + 0.5f + 2.0e-6f * (fabsf(cx) + fabsf(cy) + hx + hy);
+    };
+    auto bcast = [](float v, uint32_t src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src)); };
+    float rcx, rcy, rrad;
+    disc(bcast(xy, 0), bcast(xy, 31), bcast(xy, 63), bcast(xy, 32), rcx, rcy, rrad);
+    // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding.
+    // cull == 0 (ctx option "sdf_cull", tests): no segment is ever dropped or skipped
+    const float reach = cull ? 8.0f / scale * 1.02f + 1.0f : 3.0e+37f;
+    const float reach2 = reach * reach;
+    const uint32_t s0 = glyph_seg_start[job.glyph], s1 = glyph_seg_start[job.glyph + 1];
+    uint32_t touched = 0u;                       // quads that hold minima in s_best (wave-uniform, one bit per quad)
+    bool have_quads = false;
+    float qcx = 0.0f, qcy = 0.0f, qrad = 0.0f;   // the disc of quad (lane & 15)
+    for (uint32_t base = s0; base < s1; base += SDF_BLOCK) {
+        const bool last = base + SDF_BLOCK >= s1;
+        // ---- stage the block's segments that are within reach of the region
+        const uint32_t s = base + lane;
+        bool keep = false;
+        float c[6];
+        Obb ob = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < SDF_BLOCK && s < s1) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(seg_pts + 6u * (size_t)s);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            c[0] = (float)(int16_t)(w0 & 0xffffu); c[1] = (float)(int16_t)(w0 >> 16);
+            c[2] = (float)(int16_t)(w1 & 0xffffu); c[3] = (float)(int16_t)(w1 >> 16);
+            c[4] = (float)(int16_t)(w2 & 0xffffu); c[5] = (float)(int16_t)(w2 >> 16);
+            ob = make_obb(c);
+            keep = !cull || obb_gap2(c[0], c[1], ob.tx, ob.ty, ob.alo, ob.ahi, ob.blo, ob.bhi, rcx, rcy, rrad) <= reach2;
+        }
+        const unsigned long long km = __ballot(keep);
+        const uint32_t n = (uint32_t)__popcll(km);
+        if (n == 0u && !(last && touched)) continue;
+        __syncthreads();                         // (one wave: the previous block's readers are done with the list; s_xy is written)
+        if (keep) {
+            float *e = s_seg + SDF_ENTRY * __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            const float ax = c[2] - c[0], ay = c[3] - c[1];                                     // A
+            const float bx = c[0] - 2.0f * c[2] + c[4], by = c[1] - 2.0f * c[3] + c[5];         // second difference
+            *reinterpret_cast<float4 *>(e) = make_float4(c[0], c[1], ax, ay);
+            *reinterpret_cast<float4 *>(e + 4) = make_float4(ob.tx, ob.ty, ob.alo, ob.ahi);
+            *reinterpret_cast<float4 *>(e + 8) = make_float4(ob.blo, ob.bhi, bx, by);
+            float bxk[8], byk[8];
+#pragma unroll
+            for (int k = 1; k <= 8; ++k) {
+                const float t = (float)k * 0.125f;
+                bxk[k - 1] = c[0] + 2.0f * t * ax + t * t * bx;
+                byk[k - 1] = c[1] + 2.0f * t * ay + t * t * by;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                *reinterpret_cast<float4 *>(e + 12 + 4 * k) = make_float4(bxk[4 * k], bxk[4 * k + 1], bxk[4 * k + 2], bxk[4 * k + 3]);
+                *reinterpret_cast<float4 *>(e + 20 + 4 * k) = make_float4(byk[4 * k], byk[4 * k + 1], byk[4 * k + 2], byk[4 * k + 3]);
+            }
+        }
+        if (!have_quads) {                       // (the first block that keeps anything)
+            have_quads = true;
+            const uint32_t qc = (lane & 3u) * 8u, qr = 32u + ((lane >> 2) & 3u) * 8u;
+            disc(s_xy[qc], s_xy[qc + 7u], s_xy[qr + 7u], s_xy[qr], qcx, qcy, qrad);
+        }
+        __syncthreads();
+        // ---- which list entries can reach which quad: lane (g, q) = (lane >> 4, lane & 15) tests the entries
+        // g J .. g J + J - 1 against quad q; bit j of `cm` <-> entry g J + j
+        const uint32_t J = (n + 3u) >> 2;
+        uint32_t cm = 0u;
+        for (uint32_t j = 0; j < J; ++j) {
+            const uint32_t k = (lane >> 4) * J + j;
+            if (k < n) {
+                const float *e = s_seg + SDF_ENTRY * k;
+                const float2 e0 = *reinterpret_cast<const float2 *>(e);
+                const float4 e1 = *reinterpret_cast<const float4 *>(e + 4);
+                const float2 e2 = *reinterpret_cast<const float2 *>(e + 8);
+                const bool cand = !cull || obb_gap2(e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, qcx, qcy, qrad) <= reach2;
+                cm |= (cand ? 1u : 0u) << j;
+            }
+        }
+        // ---- the region's quads
+        for (uint32_t q = 0; q < 16u; ++q) {
+            const uint32_t QX = X0 + (q & 3u) * 8u, QY = Y0 + (q >> 2) * 8u;
+            if (QX >= job.w || QY >= job.h) continue;
+            unsigned long long mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)q)
+                                    | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)(q + 16u)) << J
+                                    | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)(q + 32u)) << (2u * J)
+                                    | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)(q + 48u)) << (3u * J);
+            const bool was = (touched >> q) & 1u;
+            if (!mask && !(last && was)) continue;
+            const uint32_t x = QX + (lane & 7u), y = QY + (lane >> 3);
+            const bool valid = x < job.w && y < job.h;
+            const float qx = s_xy[(q & 3u) * 8u + (lane & 7u)], qy = s_xy[32u + (q >> 2) * 8u + (lane >> 3)];
+            // A computed curve point B(t) - q can leave the box by a few roundings of its three-term sum (each <= half
+            // an ulp of a magnitude <= 2^18 for i16 points: < 2^-6 font units, far less relative to a distant sample),
+            // and the box's own frame is rounded too (make_obb).  The box the pixel looks at is therefore grown by
+            // `slack`, so that "the computed distance is >= the box distance" holds for the ROUNDED distance too and a
+            // skipped segment can never have produced a smaller value — whatever order the segments come in.
+            const float slack = 0.5f + 2.0e-6f * (fabsf(qx) + fabsf(qy));
+            float best = was ? s_best[q * 64u + lane] : 3.402823466e+38f;
+            while (mask) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const float *e = s_seg + SDF_ENTRY * k;
+                const float2 e0 = *reinterpret_cast<const float2 *>(e);
+                const float4 e1 = *reinterpret_cast<const float4 *>(e + 4);
+                const float2 e2 = *reinterpret_cast<const float2 *>(e + 8);
+                const float g2 = obb_gap2(e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, qx, qy, slack);
+                const bool active = valid && !(cull && (g2 >= best || g2 > reach2));
+                if (!__any(active)) continue;
+                const float d2 = seg_dist2(e, qx, qy);
+                if (active && d2 < best) best = d2;
+            }
+            if (!last) {
+                s_best[q * 64u + lane] = best;
+                touched |= 1u << q;
+                continue;
+            }
+            if (!valid) continue;
+            uint8_t *px = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
+            const bool inside = *px != 0;          // the sign pass: winding != 0 at this sample
+            float d = __builtin_sqrtf(best) * scale;
+            if (!inside) d = -d;
+            float v = 16.0f * d + 128.0f;
+            v = floorf(v + 0.5f);
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            *px = (uint8_t)v;
+        }
+    }
+}
+
+hipError_t launch_sdf(const RenderArgs &a, uint32_t max_w, uint32_t max_h, int cull, hipStream_t stream)
 {
     if (a.n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
-    const uint32_t tiles_x = (max_w + 15u) / 16u, tiles_y = (max_h + 15u) / 16u;
-    const size_t grid = (size_t)a.n_jobs * tiles_x * tiles_y;
+    const uint32_t rx = (max_w + SDF_REGION - 1u) / SDF_REGION, ry = (max_h + SDF_REGION - 1u) / SDF_REGION;
+    const size_t grid = (size_t)a.n_jobs * rx * ry;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sdf_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, a.jobs, pts, seg_p0,
-                       a.glyph_seg_start, a.glyph_rec_count, a.recs, reinterpret_cast<uint8_t *>(a.out),
-                       a.out_stride, tiles_x, tiles_y, a.phase_center, cull);
+    hipLaunchKernelGGL(sdf_kernel, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.seg_pts, a.glyph_seg_start,
+                       reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
     return hipGetLastError();
 }
 

@@ -600,7 +600,7 @@ def test_full_size_properties_config4_shard(ctx, oracle):
 
 def test_sdf_config5_cells_and_exact_culls(ctx, oracle):
     """BASELINE configs[4] shape: SDF at 512 x 512 per glyph (two 256-pixel strips per cell) on 3 synthetic S = 64
-    glyphs against the CPU twin; and the claim behind the kernel's two culls (a tile drops segments beyond the
+    glyphs against the CPU twin; and the claim behind the kernel's culls (a region and a quad drop segments beyond the
     encoding's reach, a pixel skips segments no nearer than its best so far): with the culls switched off (ctx
     option sdf_cull = 0) the bytes are the same — on the 512^2 cells and on 1 500 small random cells."""
     gs = synth_glyphset(3, 64, first_index=5151)
@@ -813,6 +813,22 @@ def test_sdf_matches_its_cpu_twin(ctx, oracle, ascii_set, center):
     got2, ref2 = _batch_both(ctx, oracle, sg2, sj2, fr.FR_SDF_U8, atlas_shape(2, 224, 2), 1, center, threads=16)
     assert np.array_equal(got2, ref2)
     assert (got2 == 0).any() and (got2 == 255).any()
+    # glyphs of more than 64 segments (the kernel reads 64 at a time and parks the minima in LDS in between), in cells
+    # whose sides are no multiple of its 8-pixel quads or 32-pixel regions; culls on == culls off == the twin
+    for big, cw, ch in ((synth_glyphset(3, 200, first_index=5200), 88, 72), (stroke_glyphset(2, 256, first_index=5300), 100, 117)):
+        sc = np.float32(min(cw, ch) - 8) / np.float32(2048)
+        bj = rg.make_jobs([(g, -5, ch - 4, cw, ch, g * cw, 0, sc) for g in range(len(big))])
+        got3, ref3 = _batch_both(ctx, oracle, big, bj, fr.FR_SDF_U8, (ch, cw * len(big)), 1, center, threads=16)
+        assert np.array_equal(got3, ref3)
+        try:
+            ctx.set_option("sdf_cull", 0)
+            plain = np.zeros_like(got3)
+            dg = fr.DeviceGlyphSet(ctx, big)
+            rg.render_batch(dg, bj, fr.FR_SDF_U8, plain, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+            dg.close()
+        finally:
+            ctx.set_option("sdf_cull", 1)
+        assert np.array_equal(plain, ref3)
     # sign agrees with the coverage mask: inside -> >= 128, outside -> <= 128 (|d| < 1/32 px rounds to 128)
     mask = np.zeros_like(got)
     rg.render_batch(fr.DeviceGlyphSet(ctx, sg), sj, fr.FR_MASK_NONZERO, mask, 1, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
