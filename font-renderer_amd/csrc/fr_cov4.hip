@@ -117,6 +117,9 @@ void cov4_kernel(const RenderArgs A)
     if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
     if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
     const uint32_t jidx = bid;
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 9
+    if (A.n_jobs != 0xffffffffu) return;                                                        // timing-only: the launch alone
+#endif
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * SW;
     const uint32_t band_first = bgrp * A.bands_per_wg;
@@ -125,6 +128,16 @@ void cov4_kernel(const RenderArgs A)
     const int phase = A.phase_center;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
 
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 10
+    if (A.n_jobs != 0xffffffffu) { if (job.w + seg0 + nseg == 0x7fffffffu) reinterpret_cast<uint8_t *>(A.out)[0] = 1; return; }   // timing-only: launch + job + segment range
+#endif
+#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 11
+    if (A.n_jobs != 0xffffffffu) {                                                              // timing-only: ... + my segment's points
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(A.seg_pts + 6u * (size_t)(seg0 + min(tid >> 1, nseg - 1u)));
+        if (w[0] + w[1] + w[2] + job.w == 0x7fffffffu) reinterpret_cast<uint8_t *>(A.out)[0] = 1;
+        return;
+    }
+#endif
     float *s_cxp = reinterpret_cast<float *>(smem);
     Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
     unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
