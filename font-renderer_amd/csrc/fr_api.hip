@@ -24,7 +24,7 @@ hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, hipStream_t);
 hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
-hipError_t launch_sdf(const RenderArgs &, uint32_t, uint32_t, int cull, hipStream_t);
+hipError_t launch_sdf(const RenderArgs &, uint32_t, uint32_t, uint32_t max_seg, int cull, hipStream_t);
 void launch_glyph_info(const int16_t *, const uint32_t *, const uint32_t *, uint32_t, int, uint8_t *,
                        uint8_t *, hipStream_t);
 void launch_exact_winding(const int16_t *, const uint32_t *, const uint8_t *, const uint8_t *,
@@ -578,7 +578,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.jobs = plan->d_jobs;
         a.job_seg = plan->d_job_seg;
         a.n_jobs = plan->n_jobs;
-        HIP_TRY(fr::launch_sdf(a, plan->max_w, plan->max_h, (int)plan->ctx->sdf_cull, plan->ctx->stream));
+        HIP_TRY(fr::launch_sdf(a, plan->max_w, plan->max_h, plan->gs->max_seg_per_glyph, (int)plan->ctx->sdf_cull, plan->ctx->stream));
     }
     return FR_OK;
 }

@@ -119,18 +119,22 @@ __device__ __forceinline__ float obb_gap2(float p0x, float p0y, float tx, float 
     return da * da + db * db;
 }
 
-__global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const int16_t *__restrict__ seg_pts,
-                                                 const uint32_t *__restrict__ glyph_seg_start, uint8_t *__restrict__ out,
+// MULTI: some glyph of the batch has more than SDF_BLOCK segments (the minima then wait in 4 KB of LDS between blocks;
+// without them 21 waves fit a CU instead of 13)
+template <bool MULTI>
+__global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ job_seg,
+                                                 const int16_t *__restrict__ seg_pts, uint8_t *__restrict__ out,
                                                  uint64_t out_stride, uint32_t regions_x, uint32_t regions_y,
                                                  int phase_center, int cull)
 {
     __shared__ __attribute__((aligned(16))) float s_seg[SDF_BLOCK * SDF_ENTRY];
-    __shared__ float s_best[16u * 64u];         // per-pixel minima of the region between blocks of segments
+    __shared__ float s_best[MULTI ? 16u * 64u : 1u];     // per-pixel minima of the region between blocks of segments
     __shared__ float s_xy[64];                  // the region's 32 sample abscissae, then its 32 sample ordinates
     uint32_t bid = blockIdx.x;
     const uint32_t rxi = bid % regions_x; bid /= regions_x;
     const uint32_t ryi = bid % regions_y;
-    const Job job = jobs[bid / regions_y];
+    const uint32_t jidx = bid / regions_y;
+    const Job job = jobs[jidx];
     const uint32_t X0 = rxi * SDF_REGION, Y0 = ryi * SDF_REGION;
     if (X0 >= job.w || Y0 >= job.h) return;
     const uint32_t lane = threadIdx.x;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     // cull == 0 (ctx option "sdf_cull", tests): no segment is ever dropped or skipped
     const float reach = cull ? 8.0f / scale * 1.02f + 1.0f : 3.0e+37f;
     const float reach2 = reach * reach;
-    const uint32_t s0 = glyph_seg_start[job.glyph], s1 = glyph_seg_start[job.glyph + 1];
+    const uint32_t s0 = job_seg[2u * (size_t)jidx], s1 = s0 + job_seg[2u * (size_t)jidx + 1u];      // (loaded beside the job, not after it)
     uint32_t touched = 0u;                       // quads that hold minima in s_best (wave-uniform, one bit per quad)
     bool have_quads = false;
     float qcx = 0.0f, qcy = 0.0f, qrad = 0.0f;   // the disc of quad (lane & 15)
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
             // `slack`, so that "the computed distance is >= the box distance" holds for the ROUNDED distance too and a
             // skipped segment can never have produced a smaller value — whatever order the segments come in.
             const float slack = 0.5f + 2.0e-6f * (fabsf(qx) + fabsf(qy));
-            float best = was ? s_best[q * 64u + lane] : 3.402823466e+38f;
+            float best = (MULTI && was) ? s_best[q * 64u + lane] : 3.402823466e+38f;
             while (mask) {
                 const uint32_t k = (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
@@ -251,10 +255,14 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
                 const float g2 = obb_gap2(e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, qx, qy, slack);
                 const bool active = valid && !(cull && (g2 >= best || g2 > reach2));
                 if (!__any(active)) continue;
+#if defined(FR_SDF_ABLATE) && FR_SDF_ABLATE == 1
+                const float d2 = cull == 7 ? seg_dist2(e, qx, qy) : g2 + 1.0f;                  // timing-only: no distance evaluation
+#else
                 const float d2 = seg_dist2(e, qx, qy);
+#endif
                 if (active && d2 < best) best = d2;
             }
-            if (!last) {
+            if (MULTI && !last) {
                 s_best[q * 64u + lane] = best;
                 touched |= 1u << q;
                 continue;
@@ -272,14 +280,18 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     }
 }
 
-hipError_t launch_sdf(const RenderArgs &a, uint32_t max_w, uint32_t max_h, int cull, hipStream_t stream)
+hipError_t launch_sdf(const RenderArgs &a, uint32_t max_w, uint32_t max_h, uint32_t max_seg, int cull, hipStream_t stream)
 {
     if (a.n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
     const uint32_t rx = (max_w + SDF_REGION - 1u) / SDF_REGION, ry = (max_h + SDF_REGION - 1u) / SDF_REGION;
     const size_t grid = (size_t)a.n_jobs * rx * ry;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sdf_kernel, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.seg_pts, a.glyph_seg_start,
-                       reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
+    if (max_seg > SDF_BLOCK)
+        hipLaunchKernelGGL(sdf_kernel<true>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
+                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
+    else
+        hipLaunchKernelGGL(sdf_kernel<false>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
+                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
     return hipGetLastError();
 }
 

@@ -802,6 +802,11 @@ def test_sdf_matches_its_cpu_twin(ctx, oracle, ascii_set, center):
     got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_SDF_U8, (3 * 64, 8 * 64), 1, center, threads=16)
     assert np.array_equal(got, ref)
     assert got.min() == 0 and got.max() > 140
+    # the empty glyph (' ': no segment, every byte 0) next to its neighbours, in cells smaller than one 32-pixel region row
+    i0 = ascii_set.find("STIX", " ")
+    ej = cell_jobs(gs, 40, 30, ascii_set.g_upm, 4, first_glyph=i0, n_glyphs=4)
+    got0, ref0 = _batch_both(ctx, oracle, gs, ej, fr.FR_SDF_U8, (40, 160), 1, center, threads=4)
+    assert np.array_equal(got0, ref0) and not got0[:, :40].any()
     sg = synth_glyphset(6, 64, first_index=5000)
     sj = cell_jobs(sg, 96, 96, 2048, 3)
     got, ref = _batch_both(ctx, oracle, sg, sj, fr.FR_SDF_U8, atlas_shape(6, 96, 3), 1, center, threads=16)
