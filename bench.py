@@ -245,7 +245,8 @@ def main():
         except Exception:
             traffic = None
     if mode == fr.FR_SDF_U8:
-        kname = "fr::render_kernel<COVERAGE_U8,1> + fr::sdf_kernel"
+        sign = "fr::win1_kernel<mask>" if pstats["jobs_general"] == 0 else ("fr::render_kernel<COVERAGE_U8,1>" if pstats["jobs_cov4"] == 0 else "fr::win1_kernel<mask> + fr::render_kernel<COVERAGE_U8,1>")
+        kname = f"{sign} (sign pass) + fr::sdf_kernel"
     elif pstats["jobs_general"] == 0 and mode == fr.FR_COVERAGE_U8 and n == 4:
         kname = f"fr::cov4_kernel<{4 if wl['cell'] % 256 == 0 else 3},32>"
     elif pstats["jobs_general"] == 0:

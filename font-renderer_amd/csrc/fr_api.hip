@@ -78,6 +78,9 @@ struct fr_ctx {
     uint32_t cov4 = 1;           // 16-sample coverage of uniform cells takes cov4_kernel (fr_cov4.hip) where it fits
     uint32_t zero_copy = 0;      // fr_render_glyph: render small glyphs from / into pinned host memory directly (measured: no faster than two small copies; off)
     uint32_t sdf_cull = 1;       // FR_SDF_U8: drop segments that cannot change a tile / a pixel (exact; 0 = look at all, for tests)
+    uint32_t overlap = 1;        // a mixed plan's few large glyphs (general kernel) run beside the cov4 / win1 part on a second stream
+    hipStream_t aux = nullptr;   // that second stream and the fork / join events, created on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scratch of the single-glyph entry point (fr_render_glyph): one device arena and one host staging
     // buffer, grown on demand and reused across calls
     unsigned char *arena = nullptr;
@@ -124,7 +127,7 @@ extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_last_error(void) { return g_err; }
-const char *fr_build_id(void) { return "r02.6"; }
+const char *fr_build_id(void) { return "r02.7"; }
 
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
 {
@@ -158,6 +161,9 @@ void fr_ctx_destroy(fr_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -186,6 +192,7 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
     if (!strcmp(key, "cov4")) { ctx->cov4 = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "sdf_cull")) { ctx->sdf_cull = value ? 1u : 0u; return FR_OK; }
+    if (!strcmp(key, "overlap")) { ctx->overlap = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "zero_copy")) { ctx->zero_copy = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "min_wgs")) {
         if (value < 1 || value > (1 << 24)) return fail(FR_E_INVALID, "min_wgs out of range");
@@ -544,14 +551,41 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.bands_per_wg = bpw;
         a.band_groups = (bands + bpw - 1) / bpw;
     };
+    // A mixed plan: the jobs of the general kernel (a real font's few glyphs of more than 256 segments) are a short
+    // kernel with a long critical path — forked onto a second stream so that it runs beside the cov4 / win1 part
+    // instead of after it (the jobs' cells are disjoint); joined before anything else touches the output.
+    fr_ctx *const ctx = plan->ctx;
+    hipStream_t gst = ctx->stream;
+    const bool forked = ctx->overlap && n_fast && n_gen;
+    if (forked) {
+        if (!ctx->aux) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        gst = ctx->aux;
+    }
     // a render always starts from the glyph POINTS: inside the kernels (fused) or by re-running the stand-alone
     // precompute first, for the glyphs that need it
     if (n_gen && !a.fused)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, nullptr, plan->gs->n_glyphs,
-                           plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
+                           plan->gs->d_recs, plan->gs->d_rec_count, gst);
     else if (n_gen && plan->n_large)
         fr::launch_prepare(plan->gs->d_pts, plan->gs->d_seg_p0, plan->gs->d_glyph_seg_start, plan->d_large, plan->n_large,
-                           plan->gs->d_recs, plan->gs->d_rec_count, plan->ctx->stream);
+                           plan->gs->d_recs, plan->gs->d_rec_count, gst);
+    if (n_gen) {
+        a.jobs = plan->d_jobs + n_fast;
+        a.job_seg = plan->d_job_seg + 2u * (size_t)n_fast;
+        a.n_jobs = n_gen; a.bands = plan->gen_bands; a.strips = plan->gen_strips; a.uniform = plan->uniform ? 1u : 0u;
+        split_bands(fr::render_wg_waves(), n_gen, plan->gen_bands, plan->gen_strips);
+        // SDF, sign first: the 1-sample coverage (255 where the reference's winding is non-zero, same sample points)
+        // lands in the output; the distance kernel reads it and overwrites it
+        if (sdf) HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, gst));
+        else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, gst));
+    }
+    if (forked) HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux));
     for (int part = 0; part < 2; ++part) {
         // cov4_kernel: the jobs that fit 256 record slots (four workgroups per CU), then those that need 512 (three)
         const uint32_t first = part ? plan->n_fast256 : 0u, cnt = part ? n_fast - plan->n_fast256 : plan->n_fast256;
@@ -564,16 +598,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, part ? 512u : 256u, plan->ctx->stream));
         else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), part ? 512u : 256u, plan->ctx->stream));
     }
-    if (n_gen) {
-        a.jobs = plan->d_jobs + n_fast;
-        a.job_seg = plan->d_job_seg + 2u * (size_t)n_fast;
-        a.n_jobs = n_gen; a.bands = plan->gen_bands; a.strips = plan->gen_strips; a.uniform = plan->uniform ? 1u : 0u;
-        split_bands(fr::render_wg_waves(), n_gen, plan->gen_bands, plan->gen_strips);
-        // SDF, sign first: the 1-sample coverage (255 where the reference's winding is non-zero, same sample points)
-        // lands in the output; the distance kernel reads it and overwrites it
-        if (sdf) HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, plan->ctx->stream));
-        else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, plan->ctx->stream));
-    }
+    if (forked) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (sdf) {
         a.jobs = plan->d_jobs;
         a.job_seg = plan->d_job_seg;
