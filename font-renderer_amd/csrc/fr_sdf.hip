@@ -23,7 +23,8 @@
 //   region : the wave reads the glyph's segments 64 at a time (one per lane, 12 bytes) and keeps those within
 //            reach of the region's sample box — ballot + lane-prefix compaction into an LDS list that also
 //            holds what does not depend on the sample: A, the second difference and the probe points B(k/8);
-//   quad   : lane k tests list entry k against the quad's sample box; the ballot is the quad's candidate set.
+//   quad   : the list's entries against the 16 quads' sample boxes (4 entries x 16 quads per step, each box projected
+//            onto the segment's frame); the ballots are the quads' candidate sets.
 //            A quad without candidates keeps the byte the sign pass left (255 / 0 — what the encoding gives
 //            for "farther than 8 pixels"), so nothing is read or written for it;
 //   pixel  : per candidate, the pixel's own box distance against the reach and against the best so far.
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     const uint32_t s0 = job_seg[2u * (size_t)jidx], s1 = s0 + job_seg[2u * (size_t)jidx + 1u];      // (loaded beside the job, not after it)
     uint32_t touched = 0u;                       // quads that hold minima in s_best (wave-uniform, one bit per quad)
     bool have_quads = false;
-    float qcx = 0.0f, qcy = 0.0f, qrad = 0.0f;   // the disc of quad (lane & 15)
+    float qcx = 0.0f, qcy = 0.0f, qhx = 0.0f, qhy = 0.0f, qpad = 0.0f;   // the sample box of quad (lane & 15): centre, half sides, slack
     for (uint32_t base = s0; base < s1; base += SDF_BLOCK) {
         const bool last = base + SDF_BLOCK >= s1;
         // ---- stage the block's segments that are within reach of the region
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
         if (!have_quads) {                       // (the first block that keeps anything)
             have_quads = true;
             const uint32_t qc = (lane & 3u) * 8u, qr = 32u + ((lane >> 2) & 3u) * 8u;
-            disc(s_xy[qc], s_xy[qc + 7u], s_xy[qr + 7u], s_xy[qr], qcx, qcy, qrad);
+            const float xa = s_xy[qc], xb = s_xy[qc + 7u], ya = s_xy[qr + 7u], yb = s_xy[qr];
+            qcx = 0.5f * (xa + xb); qcy = 0.5f * (ya + yb);
+            qhx = 0.5f * (xb - xa) * 1.001f; qhy = 0.5f * (yb - ya) * 1.001f;
+            qpad = 0.5f + 2.0e-6f * (fabsf(qcx) + fabsf(qcy) + qhx + qhy);                  // >= the pixel test's slack anywhere in the quad
         }
         __syncthreads();
         // ---- which list entries can reach which quad: lane (g, q) = (lane >> 4, lane & 15) tests the entries
@@ -221,7 +225,14 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
                 const float2 e0 = *reinterpret_cast<const float2 *>(e);
                 const float4 e1 = *reinterpret_cast<const float4 *>(e + 4);
                 const float2 e2 = *reinterpret_cast<const float2 *>(e + 8);
-                const bool cand = !cull || obb_gap2(e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, qcx, qcy, qrad) <= reach2;
+                // the quad's box seen in the segment's frame: its half extents along tau and n (a box in that frame
+                // that holds the quad's sample points; tighter than the disc about them unless the segment is diagonal)
+                const float atx = fabsf(e1.x), aty = fabsf(e1.y);
+                const float pa = qhx * atx + qhy * aty + qpad, pb = qhx * aty + qhy * atx + qpad;
+                const float wx = qcx - e0.x, wy = qcy - e0.y;
+                const float fa = wx * e1.x + wy * e1.y, fb = wy * e1.x - wx * e1.y;
+                const float da = fmaxf(fmaxf(e1.z - fa, fa - e1.w) - pa, 0.0f), db = fmaxf(fmaxf(e2.x - fb, fb - e2.y) - pb, 0.0f);
+                const bool cand = !cull || da * da + db * db <= reach2;
                 cm |= (cand ? 1u : 0u) << j;
             }
         }
