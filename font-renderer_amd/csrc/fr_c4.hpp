@@ -12,7 +12,7 @@ namespace fr {
 #define FR_C4_OCC 4
 #endif
 #ifndef FR_C4_PCAP
-#define FR_C4_PCAP 384
+#define FR_C4_PCAP 448
 #endif
 #ifndef FR_C4_LSTRIDE
 #define FR_C4_LSTRIDE 36

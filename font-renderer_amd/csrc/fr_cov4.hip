@@ -188,14 +188,13 @@ void cov4_kernel(const RenderArgs A)
         s_cy[lane] = cy;
         s_cnt[lane] = 0u;
 
-        // ---- layout + evaluation, in rounds of at most PCAP (record, row) pairs over a span of the band's rows
-        uint32_t rr0 = 0;                          // first row (in the band) not laid out yet
-        while (rr0 < 64u) {
-            uint32_t span = 64u - rr0;
-            uint32_t c[RPL], r0[RPL], csum, incl, tot;
-            for (;;) {
-                const uint32_t lo = row_b0 + rr0, hi = lo + span;
-                csum = 0;
+        // ---- layout + evaluation.  The band's (record, row) pairs form ONE sequence, record by record (lane by lane,
+        // a lane's records in order); it is walked in chunks of PCAP pairs — only the markers are per chunk, the row
+        // offsets and the running record index carry over — 64 pairs per trip, every trip but the last one full.
+        {
+            uint32_t c[RPL], r0[RPL], csum = 0;
+            {
+                const uint32_t lo = row_b0, hi = row_b0 + 64u;
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
                     r0[i] = max(rra[i], lo);
@@ -203,42 +202,52 @@ void cov4_kernel(const RenderArgs A)
                     c[i] = r1 > r0[i] ? r1 - r0[i] : 0u;
                     csum += c[i];
                 }
-                incl = c4_wave_incl_add(csum);
-                tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (tot <= (uint32_t)C4_PCAP || span == 1u) break;      // (one row has <= 256 pairs)
-                span >>= 1;
             }
+            const uint32_t incl = c4_wave_incl_add(csum);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (tot) {
-                // markers: slot `off` of the pair sequence holds k + 1 where record k's run starts, 0 elsewhere
+                const uint32_t off0 = incl - csum;
+                {
+                    uint32_t off = off0, ro[RPL];
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        ro[i] = (r0[i] - row_b0 - off) & 0xffffu;
+                        off += c[i];
+                    }
+                    // my records' row offsets sit side by side: one store
+                    if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
+                    else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                    else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                }
+                const uint32_t npairs = tot;
+                uint32_t carry = 0u;               // record index (+ 1) of the last pair walked so far
+              for (uint32_t base = 0; base < npairs; base += (uint32_t)C4_PCAP) {
+                // markers: slot `off - base` of the chunk holds k + 1 where record k's run starts, 0 elsewhere
                 if (C4_PCAP >= 512 || lane < C4_PCAP / 8) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
                 c4_wave_lds_sync();
-                uint32_t off = incl - csum;
-                uint32_t ro[RPL];
+                {
+                    uint32_t off = off0 - base;    // (wraps below the chunk: an unsigned compare takes both ends)
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    if (c[i]) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
-                    ro[i] = (r0[i] - row_b0 - off) & 0xffffu;
-                    off += c[i];
+                    for (int i = 0; i < RPL; ++i) {
+                        if (c[i] && off < (uint32_t)C4_PCAP) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
+                        off += c[i];
+                    }
                 }
-                // my records' row offsets sit side by side: one store
-                if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
-                else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
-                else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
                 c4_wave_lds_sync();
-                const uint32_t npairs = tot;
+                const uint32_t nhere = min(npairs - base, (uint32_t)C4_PCAP);
                 // one pair per lane per trip; the marker max-scan of the NEXT 64 pairs is issued before the
                 // current 64 are evaluated (an independent chain that fills the evaluation's wait states)
-                uint32_t k_cur = c4_wave_incl_max((uint32_t)s_pairs[lane]);
-                uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
+                uint32_t k_cur = max(c4_wave_incl_max((uint32_t)s_pairs[lane]), carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
 #if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 3
-                for (uint32_t p0 = 0; p0 < npairs && A.n_jobs == 0xffffffffu; p0 += 64u) {     // timing-only: pairs laid out, never evaluated
+                for (uint32_t p0 = 0; p0 < nhere && A.n_jobs == 0xffffffffu; p0 += 64u) {      // timing-only: pairs laid out, never evaluated
 #else
-                for (uint32_t p0 = 0; p0 < npairs; p0 += 64u) {
+                for (uint32_t p0 = 0; p0 < nhere; p0 += 64u) {
 #endif
                     const uint32_t pn = min(p0 + 64u + lane, (uint32_t)C4_PCAP - 1u);
                     const uint32_t s_next = c4_wave_incl_max((uint32_t)s_pairs[pn]);
                     {
-                        const uint32_t p = p0 + lane, k1 = k_cur;
+                        const uint32_t p = base + p0 + lane, k1 = k_cur;
                         const bool livep = p < npairs;
                         // (a lane past the end decodes the last record and a row that may lie outside the band:
                         // it computes like the others and is kept from the table walk and the append)
@@ -311,8 +320,8 @@ void cov4_kernel(const RenderArgs A)
                     carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
                 }
                 c4_wave_lds_sync();
+              }
             }
-            rr0 += span;
         }
 #if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 4
         if (A.n_jobs != 0xffffffffu) continue;                                                  // timing-only: set-up, layout and evaluation alone
