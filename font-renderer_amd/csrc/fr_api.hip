@@ -110,8 +110,8 @@ struct fr_plan {
     uint32_t n_jobs = 0;
     // jobs cov4_kernel takes (fr_cov4.hip: 16-sample coverage, uniform cells, <= 256 root records): the first n_fast
     // entries of d_jobs / d_job_seg; the general kernel renders the other n_jobs - n_fast
-    uint32_t n_fast = 0;               // (of which the first n_fast256 need <= 256 record slots, the rest <= 512)
-    uint32_t n_fast256 = 0;
+    uint32_t n_fast = 0;               // (of which the first n_fast128 need <= 128 record slots, up to n_fast256 <= 256, the rest <= 512)
+    uint32_t n_fast128 = 0, n_fast256 = 0;
     uint32_t fast_bands = 0, fast_strips = 0, gen_bands = 0, gen_strips = 0;
     bool gen_uniform = false;
     fr_raster_params params{};
@@ -432,16 +432,20 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
                          (params->mode == FR_COVERAGE_U8 && n == 1u) || params->mode == FR_SDF_U8;   // (SDF: its sign pass)
         const bool mode_ok = ctx->cov4 && (sw == 128u || sw == 256u) && ((params->mode == FR_COVERAGE_U8 && n == 4u) || one);
         const uint32_t max_h_fast = one ? 2048u : 512u;                  // (sample rows <= 2048: 12-bit row fields)
-        std::vector<uint32_t> mid, slow;
+        std::vector<uint32_t> mid256, mid, slow;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             const fr_job &jb = jobs[j];
             const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
             const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= max_h_fast &&
                               nsg <= fr::cov4_max_segments();
-            if (fast && gs->h_root_bound[jb.glyph] <= 256u) order[n_fast++] = j;
+            if (fast && gs->h_root_bound[jb.glyph] <= 128u) order[n_fast++] = j;
+            else if (fast && gs->h_root_bound[jb.glyph] <= 256u) mid256.push_back(j);
             else if (fast) mid.push_back(j);           // (<= 256 segments: <= 512 candidate roots)
             else slow.push_back(j);
         }
+        p->n_fast128 = n_fast;
+        std::copy(mid256.begin(), mid256.end(), order.begin() + n_fast);
+        n_fast += (uint32_t)mid256.size();
         p->n_fast256 = n_fast;
         std::copy(mid.begin(), mid.end(), order.begin() + n_fast);
         n_fast += (uint32_t)mid.size();
@@ -586,17 +590,20 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, gst));
     }
     if (forked) HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux));
-    for (int part = 0; part < 2; ++part) {
-        // cov4_kernel: the jobs that fit 256 record slots (four workgroups per CU), then those that need 512 (three)
-        const uint32_t first = part ? plan->n_fast256 : 0u, cnt = part ? n_fast - plan->n_fast256 : plan->n_fast256;
+    for (int part = 0; part < 3; ++part) {
+        // cov4_kernel / win1_kernel: the jobs that fit 128 record slots (two records per lane), 256 (four; both four
+        // workgroups per CU), then those that need 512 (eight per lane, three workgroups per CU)
+        const uint32_t first = part == 0 ? 0u : (part == 1 ? plan->n_fast128 : plan->n_fast256);
+        const uint32_t cnt = (part == 0 ? plan->n_fast128 : (part == 1 ? plan->n_fast256 : n_fast)) - first;
+        const uint32_t rec_cap = part == 0 ? 128u : (part == 1 ? 256u : 512u);
         if (!cnt) continue;
         a.jobs = plan->d_jobs + first;
         a.job_seg = plan->d_job_seg + 2u * (size_t)first;
         a.n_jobs = cnt; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
         split_bands(fr::cov4_wg_waves(), cnt, plan->fast_bands, plan->fast_strips);
         const int pm = plan->params.mode;
-        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, part ? 512u : 256u, plan->ctx->stream));
-        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), part ? 512u : 256u, plan->ctx->stream));
+        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, rec_cap, plan->ctx->stream));
+        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), rec_cap, plan->ctx->stream));
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (sdf) {

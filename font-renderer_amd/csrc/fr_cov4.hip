@@ -90,7 +90,7 @@ struct C4Lds {
     static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
     static constexpr uint32_t OFF_ROFF = OFF_CNT + 256u;
     static constexpr uint32_t WALK = OFF_ROFF + RCAP * 2u;
-    static constexpr uint32_t WAVE = (WALK > E ? WALK : E);
+    static constexpr uint32_t WAVE = (WALK > E + NCOL * 2u ? WALK : E + NCOL * 2u);   // (E + an over-full row's 16-bit differences)
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
     static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
@@ -150,7 +150,7 @@ void cov4_kernel(const RenderArgs A)
     const float ncolf = (float)NCOL;
     // every lane keeps the row ranges of its records in registers for all its bands: records RPL*lane ...
     // (consecutive, so the record index grows along the pair sequence and the marker decode is a max-scan)
-    const bool few = rec_cnt <= 128u;              // workgroup-uniform: two records per lane are enough
+    const bool few = RPL == 2 || rec_cnt <= 128u;   // (RPL == 2: the plan sends only glyphs of <= 128 candidate roots)              // workgroup-uniform: two records per lane are enough
     const uint32_t per = few ? 2u : (uint32_t)RPL;
     uint32_t rra[RPL], rre[RPL];
 #pragma unroll
@@ -170,7 +170,7 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *s_E = wregion;
 
 #if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 5
-    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[1] + rra[RPL - 2] + rre[RPL - 1] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
+    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[RPL > 1 ? 1 : 0] + rra[RPL > 1 ? RPL - 2 : 0] + rre[RPL - 1] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
 #endif
     for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
         const uint32_t band = band0 + wave;
@@ -216,8 +216,8 @@ void cov4_kernel(const RenderArgs A)
                     }
                     // my records' row offsets sit side by side: one store
                     if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
-                    else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
-                    else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                    else if constexpr (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                    else if constexpr (RPL == 8) *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
                 }
                 const uint32_t npairs = tot;
                 uint32_t carry = 0u;               // record index (+ 1) of the last pair walked so far
@@ -560,6 +560,7 @@ void cov4_kernel(const RenderArgs A)
 
 size_t cov4_lds_bytes(int wlog, int rpl)
 {
+    if (rpl == 2) return wlog == 4 ? C4Lds<4, 2>::TOTAL : C4Lds<3, 2>::TOTAL;
     if (rpl == 4) return wlog == 4 ? C4Lds<4, 4>::TOTAL : C4Lds<3, 4>::TOTAL;
     return wlog == 4 ? C4Lds<4, 8>::TOTAL : C4Lds<3, 8>::TOTAL;
 }
@@ -597,7 +598,10 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
 hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, hipStream_t stream)
 {
     const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
-    if (rec_cap <= 256u) {
+    if (rec_cap <= 128u) {
+        if (a.strip_w == 256u) return cov4_launch_cap<4, 2>(a, grid, stream);
+        if (a.strip_w == 128u) return cov4_launch_cap<3, 2>(a, grid, stream);
+    } else if (rec_cap <= 256u) {
         if (a.strip_w == 256u) return cov4_launch_cap<4, 4>(a, grid, stream);
         if (a.strip_w == 128u) return cov4_launch_cap<3, 4>(a, grid, stream);
     } else {

@@ -82,7 +82,7 @@ void win1_kernel(const RenderArgs A)
     const float soff = phase ? 0.5f : 0.0f;
     const float joff = (float)min_xs + soff - 1.0f;
     const float ncolf = (float)NCOL;
-    const bool few = rec_cnt <= 128u;
+    const bool few = RPL == 2 || rec_cnt <= 128u;   // (RPL == 2: the plan sends only glyphs of <= 128 candidate roots)
     const uint32_t per = few ? 2u : (uint32_t)RPL;
     uint32_t rra[RPL], rre[RPL];
 #pragma unroll
@@ -149,8 +149,8 @@ void win1_kernel(const RenderArgs A)
                     off += c[i];
                 }
                 if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
-                else if (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
-                else *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                else if constexpr (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
+                else if constexpr (RPL == 8) *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
                 c4_wave_lds_sync();
                 const uint32_t npairs = tot;
                 uint32_t k_cur = c4_wave_incl_max((uint32_t)s_pairs[lane]);
@@ -389,7 +389,10 @@ static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hip
 hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream)
 {
     const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
-    if (rec_cap <= 256u) {
+    if (rec_cap <= 128u) {
+        if (a.strip_w == 256u) return win1_launch_mode<4, 2>(a, mode, grid, stream);
+        if (a.strip_w == 128u) return win1_launch_mode<3, 2>(a, mode, grid, stream);
+    } else if (rec_cap <= 256u) {
         if (a.strip_w == 256u) return win1_launch_mode<4, 4>(a, mode, grid, stream);
         if (a.strip_w == 128u) return win1_launch_mode<3, 4>(a, mode, grid, stream);
     } else {
