@@ -571,6 +571,8 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         HIP_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         gst = ctx->aux;
     }
+    // (whatever fails between the fork and the join: the context's stream still waits for the second one)
+    auto launch_parts = [&]() -> int {
     // a render always starts from the glyph POINTS: inside the kernels (fused) or by re-running the stand-alone
     // precompute first, for the glyphs that need it
     if (n_gen && !a.fused)
@@ -589,7 +591,6 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         if (sdf) HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, gst));
         else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, gst));
     }
-    if (forked) HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux));
     for (int part = 0; part < 3; ++part) {
         // cov4_kernel / win1_kernel: the jobs that fit 128 record slots (two records per lane), 256 (four; both four
         // workgroups per CU), then those that need 512 (eight per lane, three workgroups per CU)
@@ -605,7 +606,14 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, rec_cap, plan->ctx->stream));
         else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), rec_cap, plan->ctx->stream));
     }
-    if (forked) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return FR_OK;
+    };
+    const int rc_parts = launch_parts();
+    if (forked) {
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
+    if (rc_parts) return rc_parts;
     if (sdf) {
         a.jobs = plan->d_jobs;
         a.job_seg = plan->d_job_seg;

@@ -97,6 +97,12 @@ def test_mixed_glyph_sizes_in_one_plan(ctx, oracle):
         jobs = cell_jobs(gs, cell, cell, 2048, 5)
         got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(len(gs), cell, 5), n, True, threads=16)
         assert np.array_equal(got, ref), (cell, n)
+        if cell in (128, 256):
+            # this plan holds all four kinds of job (<= 128 / 256 / 512 candidate roots: cov4_kernel with 2 / 4 / 8 records per
+            # lane; 520 segments: the general kernel, forked onto the context's second stream) — the same bytes in one stream
+            st = fr.Plan(fr.DeviceGlyphSet(ctx, gs), jobs, fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER).stats()
+            assert st["jobs_cov4"] == len(gs) - 1 and st["jobs_general"] == 1, st
+            assert np.array_equal(_render_opt(ctx, gs, jobs, atlas_shape(len(gs), cell, 5), n, True, overlap=0), ref)
     jobs = cell_jobs(gs, 64, 64, 2048, 5)
     got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_WINDING_I16, atlas_shape(len(gs), 64, 5), 1, False, threads=16)
     assert np.array_equal(got, ref)
@@ -118,7 +124,7 @@ def test_coverage_stroke_dense(ctx, oracle, segs, cell):
 
 def _render_opt(ctx, gs, jobs, shape, n, center, **opts):
     """one coverage render with context options set for its duration"""
-    defaults = {"cov4": 1, "kmax": 32, "min_wgs": 2048, "strip_px": 256}
+    defaults = {"cov4": 1, "kmax": 32, "min_wgs": 2048, "strip_px": 256, "overlap": 1}
     try:
         for k, v in opts.items():
             ctx.set_option(k, v)
