@@ -12,7 +12,7 @@ WL = {   # workload -> (kernel name fragments summed, label, algorithmic bytes p
     "c3_cjk21k_256px_s128_16spp": (["cov4_kernel<4, 32, 4>"], "fr::cov4_kernel<4,32,4>", 20992 * 65536),
     "c3_cjk21k_256px_s128_gray_debug": (["win1_kernel<4, 1, 4>"], "fr::win1_kernel<4,gray_debug,4>", 20992 * 65536),
     "c3_cjk21k_256px_s128_winding_i16": (["win1_kernel<4, 0, 4>"], "fr::win1_kernel<4,winding_i16,4>", 20992 * 65536 * 2),
-    "c5_sdf_shard_512px_s64": (["win1_kernel<4, 2, 4>", "sdf_kernel<false>"], "fr::win1_kernel<4,mask,4> (sign pass) + fr::sdf_kernel<false>", 512 * 512 * 512),
+    "c5_sdf_shard_512px_s64": (["win1_kernel<4, 2, ", "sdf_kernel<false>"], "fr::win1_kernel<4,mask> (sign pass) + fr::sdf_kernel<false>", 512 * 512 * 512),
 }
 vals = {}
 for line in open(f"{src}/pmc_summary.txt"):
