@@ -96,14 +96,94 @@ __device__ __forceinline__ void c4_wave_lds_sync()
 }
 
 
+// a settled candidate as the kernels keep it (40 bytes): row range [ra, re) in the low bits of `fr`
+__device__ __forceinline__ Rec40 c4_make_rec40(const Rec &r, uint32_t ra, uint32_t re)
+{
+    Rec40 m;
+    const bool lin = (int32_t)r.flags < 0;
+    m.a = lin ? r.c1 : r.a;
+    m.b = r.b; m.c1 = lin ? 0.0f : r.c1; m.c2 = r.c2;
+    m.ax = r.ax; m.bx = r.bx; m.p0x = r.p0x; m.rden = r.rden;
+    m.sgn = r.sqsign ? -1.0f : 1.0f;
+    const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
+    m.fr = ra | (re << 12) | (cb << 24) | (zb << 26) | (lin ? 0x80000000u : 0u);
+    return m;
+}
+
+// Set-up for glyphs of <= 32 segments (<= 64 candidate roots: one per lane of ONE wave — ASCII-like glyphs), four
+// waves.  Settling a candidate's row range costs four evaluations of the reference's acceptance at the rows around
+// the two guessed ends; with the plain set-up wave 0 would do all of it while waves 1 - 3 (and the SIMDs they sit
+// on) wait.  Here every wave prepares the same 64 candidates and looks at ONE of the four rows (wave 0: ra - 1,
+// 1: ra, 2: re - 1, 3: re); wave 0 takes the guess when the four classes confirm it — exactly the condition under
+// which record_settle's walks would not move — and walks as before otherwise.  Same records, same order.
+template <uint32_t RCAP, int N, uint32_t NCOL>
+__device__ __forceinline__ uint32_t c4_setup_small(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
+                                                   int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t Hs = job.h * (uint32_t)N;
+    RowGeom geo;
+    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+    const bool have = lane < 2u * nseg;
+    Rec r;
+    RowGuess g;
+    g.empty = true; g.ra = 1u; g.re = 0u;
+    uint32_t cls = 3u;                                  // 3: no such row / not asked — the condition it stands for holds
+    if (have) {
+        record_prep(A.seg_pts + 6u * (size_t)(seg0 + (lane >> 1)), lane & 1u, geo, r, g);
+        if (!g.empty) {
+            const uint32_t row = (wave == 0u) ? g.ra - 1u : (wave == 1u) ? g.ra : (wave == 2u) ? g.re - 1u : g.re;   // (ra - 1 wraps past the cell at ra = 0)
+            if (row < Hs && (wave != 2u || g.re > g.ra)) cls = (uint32_t)classify_row(r, geo.cy(row));
+        }
+    }
+    s_tmp[tid] = cls;
+    // exact sample abscissae of this strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
+    const int32_t min_xs = job.min_x + (int32_t)x0s;
+    for (uint32_t j = tid; j < NCOL; j += 256u)
+        s_cxp[1u + j] = ((float)(min_xs + (int32_t)(j / (uint32_t)N)) + sub_off((int)(j % (uint32_t)N), N, phase)) / job.scale;
+    if (tid == 2) s_cxp[0] = -__builtin_inff();
+    if (tid == 3) s_cxp[1u + NCOL] = __builtin_inff();
+    __syncthreads();
+    if (wave == 0u) {
+        Rec40 mine;
+        mine.fr = 0u;
+        bool live = false;
+        if (have) {
+            uint32_t ra = g.ra, re = g.re;
+            if (!g.empty) {
+                const uint32_t c0 = s_tmp[lane], c1 = s_tmp[64u + lane], c2 = s_tmp[128u + lane], c3 = s_tmp[192u + lane];
+                // record_settle would leave (ra, re) alone iff: the row above ra is rejected from above (class 2), ra is
+                // not (class <= 1), re >= ra, the row before re is accepted (class >= 1), re is below the set (class 0)
+                const bool ok = (c0 >= 2u) && (c1 <= 1u || c1 == 3u) && re >= ra && (c2 >= 1u) && (c3 == 0u || c3 == 3u);
+                if (!ok) record_settle(r, geo, ra, re);
+            }
+            live = ra < re;
+            mine = c4_make_rec40(r, ra, re);
+        }
+        // quadratic records first, linear ones last (as c4_setup)
+        const bool linr = live && (int32_t)mine.fr < 0;
+        const unsigned long long lm = __ballot(live && !linr), ll = __ballot(linr), below = (1ull << lane) - 1ull;
+        const uint32_t n_quad = (uint32_t)__popcll(lm);
+        uint32_t pos = RCAP;
+        if ((lm >> lane) & 1ull) pos = (uint32_t)__popcll(lm & below);
+        if ((ll >> lane) & 1ull) pos = n_quad + (uint32_t)__popcll(ll & below);
+        if (pos < RCAP) s_rec[pos] = mine;
+        if (lane == 0u) s_wcnt[0] = min(n_quad + (uint32_t)__popcll(ll), RCAP);
+    }
+    __syncthreads();
+    return s_wcnt[0];
+}
+
 // Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW (<= 256 segments) with the
 // exact range of this cell's sample rows that accept each (fr_records.hpp), compacted into s_rec (<= RCAP kept), and
 // the padded table of the strip's exact sample abscissae.  Two workgroup barriers.  -> number of records.
 // N: samples per pixel axis (4: cov4_kernel, 1: win1_kernel); NCOL: sample columns of the strip.
 template <uint32_t NW, uint32_t RCAP, int N, uint32_t NCOL>
 __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
-                                             int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt)
+                                             int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
 {
+    if (NW == 4u && 2u * nseg <= 64u)                                        // (workgroup-uniform; s_tmp: 1 KB, free until the bands start)
+        return c4_setup_small<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
     constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
@@ -123,13 +203,7 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
             build_record_rows(A.seg_pts + 6u * (size_t)(seg0 + (c >> 1)), c & 1u, geo, r);
             const uint32_t ra = __builtin_bit_cast(uint32_t, r.lo), re = __builtin_bit_cast(uint32_t, r.hi);
             live = ra < re;
-            const bool lin = (int32_t)r.flags < 0;
-            mine[it].a = lin ? r.c1 : r.a;
-            mine[it].b = r.b; mine[it].c1 = lin ? 0.0f : r.c1; mine[it].c2 = r.c2;
-            mine[it].ax = r.ax; mine[it].bx = r.bx; mine[it].p0x = r.p0x; mine[it].rden = r.rden;
-            mine[it].sgn = r.sqsign ? -1.0f : 1.0f;
-            const uint32_t cb = lin ? (r.flags & REC_LIN_PLUS) : 2u, zb = lin ? cb : 0u;
-            mine[it].fr = ra | (re << 12) | (cb << 24) | (zb << 26) | (lin ? 0x80000000u : 0u);
+            mine[it] = c4_make_rec40(r, ra, re);
         }
         // quadratic records first, linear ones (the a == 0 branch) last: the pair sequence follows the record order,
         // so an evaluation trip is almost always all-quadratic or all-linear and takes a body without the other's work

@@ -143,7 +143,7 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
 
-    const uint32_t rec_cnt = c4_setup<NW, RCAP, 4, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt);
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, 4, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale * 4.0f;
     const float joff = (float)min_xs * 4.0f + (phase ? 0.5f : 0.0f) - 1.0f;

@@ -191,7 +191,15 @@ __device__ __forceinline__ int classify_row(const Rec &r, float cy)
 
 // As build_record, but the bracket is this cell's exact sample-row range, written as integers
 // into the lo / hi slots of the record (ra, re).  An empty range is ra = 1, re = 0.
-__device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t root, const RowGeom &G, Rec &r)
+// In three pieces, so that a set-up with lanes to spare can look at the four rows around the guessed
+// ends in parallel (fr_c4.hpp): record_prep (fields + guesses), record_settle (the exact walk from the
+// guesses), and their composition build_record_rows.
+struct RowGuess {
+    uint32_t ra, re;     // guessed first accepted row / first row past the range, clamped to [0, rows]
+    bool empty;          // the candidate is discarded without a probe (see above)
+};
+
+__device__ __forceinline__ void record_prep(const int16_t *p, uint32_t root, const RowGeom &G, Rec &r, RowGuess &g)
 {
     const float p0x = (float)p[0], p0y = (float)p[1];
     const float p1x = (float)p[2], p1y = (float)p[3];
@@ -229,7 +237,8 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
             if (!tv_ge1) { c_stop = yv; stop_incl = true; }
         }
     }
-    uint32_t ra = 1u, re = 0u;
+    g.empty = empty;
+    g.ra = 1u; g.re = 0u;
     if (!empty) {
         // guesses: first row at / strictly below an end
         const float top = (float)G.rows;
@@ -238,19 +247,32 @@ __device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t roo
         const bool hi_incl = start_hi ? true : stop_incl, lo_incl = start_hi ? stop_incl : true;
         const float fa = hi_incl ? __builtin_ceilf(xh) : __builtin_floorf(xh) + 1.0f;    // first row accepted
         const float fe = lo_incl ? __builtin_floorf(xl) + 1.0f : __builtin_ceilf(xl);    // first row past it
-        ra = (uint32_t)fminf(fmaxf(fa, 0.0f), top);
-        re = (uint32_t)fminf(fmaxf(fe, 0.0f), top);
-        // (one trip each when the guess is right: keep the compiler from unrolling them)
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        while (ra > 0u && classify_row(r, G.cy(ra - 1u)) <= 1) --ra;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        while (ra < G.rows && classify_row(r, G.cy(ra)) == 2) ++ra;
-        if (re < ra) re = ra;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        while (re > ra && classify_row(r, G.cy(re - 1u)) == 0) --re;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        while (re < G.rows && classify_row(r, G.cy(re)) >= 1) ++re;
+        g.ra = (uint32_t)fminf(fmaxf(fa, 0.0f), top);
+        g.re = (uint32_t)fminf(fmaxf(fe, 0.0f), top);
     }
+}
+
+// the exact ends from any starting guess: walk while the class of the row says so
+__device__ __forceinline__ void record_settle(const Rec &r, const RowGeom &G, uint32_t &ra, uint32_t &re)
+{
+    // (one trip each when the guess is right: keep the compiler from unrolling them)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    while (ra > 0u && classify_row(r, G.cy(ra - 1u)) <= 1) --ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    while (ra < G.rows && classify_row(r, G.cy(ra)) == 2) ++ra;
+    if (re < ra) re = ra;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    while (re > ra && classify_row(r, G.cy(re - 1u)) == 0) --re;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    while (re < G.rows && classify_row(r, G.cy(re)) >= 1) ++re;
+}
+
+__device__ __forceinline__ void build_record_rows(const int16_t *p, uint32_t root, const RowGeom &G, Rec &r)
+{
+    RowGuess g;
+    record_prep(p, root, G, r, g);
+    uint32_t ra = g.ra, re = g.re;
+    if (!g.empty) record_settle(r, G, ra, re);
     r.lo = __builtin_bit_cast(float, ra);
     r.hi = __builtin_bit_cast(float, re);
 }
