@@ -174,6 +174,67 @@ __device__ __forceinline__ uint32_t c4_setup_small(const RenderArgs &A, const Jo
     return s_wcnt[0];
 }
 
+// The same for 33 .. 64 segments (<= 128 candidate roots: one per lane of waves 0 and 1).  Thread c + 128 h looks at the
+// rows around the upper end (h = 0: ra - 1 and ra) or the lower end (h = 1: re - 1 and re) of candidate c; the owners
+// (h = 0) take the guess when all four classes confirm it and walk otherwise.
+template <uint32_t RCAP, int N, uint32_t NCOL>
+__device__ __forceinline__ uint32_t c4_setup_mid(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
+                                                 int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t c = tid & 127u, h = tid >> 7;
+    const uint32_t Hs = job.h * (uint32_t)N;
+    RowGeom geo;
+    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+    const bool have = c < 2u * nseg;
+    Rec r;
+    RowGuess g;
+    g.empty = true; g.ra = 1u; g.re = 0u;
+    uint32_t cls0 = 3u, cls1 = 3u;                      // 3: no such row / not asked
+    if (have) {
+        record_prep(A.seg_pts + 6u * (size_t)(seg0 + (c >> 1)), c & 1u, geo, r, g);
+        if (!g.empty) {
+            const uint32_t end = h ? g.re : g.ra;       // rows end - 1 and end
+            if (end - 1u < Hs && (h == 0u || g.re > g.ra)) cls0 = (uint32_t)classify_row(r, geo.cy(end - 1u));
+            if (end < Hs) cls1 = (uint32_t)classify_row(r, geo.cy(end));
+        }
+    }
+    s_tmp[tid] = cls0 | (cls1 << 8);
+    const int32_t min_xs = job.min_x + (int32_t)x0s;
+    for (uint32_t j = tid; j < NCOL; j += 256u)
+        s_cxp[1u + j] = ((float)(min_xs + (int32_t)(j / (uint32_t)N)) + sub_off((int)(j % (uint32_t)N), N, phase)) / job.scale;
+    if (tid == 2) s_cxp[0] = -__builtin_inff();
+    if (tid == 3) s_cxp[1u + NCOL] = __builtin_inff();
+    __syncthreads();
+    Rec40 mine;
+    mine.fr = 0u;
+    bool live = false;
+    if (h == 0u && have) {
+        uint32_t ra = g.ra, re = g.re;
+        if (!g.empty) {
+            const uint32_t up = s_tmp[c], dn = s_tmp[128u + c];
+            const uint32_t c0 = up & 0xffu, c1 = up >> 8, c2 = dn & 0xffu, c3 = dn >> 8;
+            const bool ok = (c0 >= 2u) && (c1 <= 1u || c1 == 3u) && re >= ra && (c2 >= 1u) && (c3 == 0u || c3 == 3u);
+            if (!ok) record_settle(r, geo, ra, re);
+        }
+        live = ra < re;
+        mine = c4_make_rec40(r, ra, re);
+    }
+    // quadratic records first, linear ones last (as c4_setup): waves 0 and 1 hold them
+    const bool linr = live && (int32_t)mine.fr < 0;
+    const unsigned long long lm = __ballot(live && !linr), ll = __ballot(linr), below = (1ull << lane) - 1ull;
+    if (lane == 0u && wave < 2u) { s_wcnt[wave] = (uint32_t)__popcll(lm); s_wcnt[2u + wave] = (uint32_t)__popcll(ll); }
+    __syncthreads();
+    const uint32_t q0 = s_wcnt[0], q1 = s_wcnt[1], l0 = s_wcnt[2], l1 = s_wcnt[3];
+    const uint32_t n_quad = q0 + q1;
+    uint32_t pos = RCAP;
+    if ((lm >> lane) & 1ull) pos = (wave ? q0 : 0u) + (uint32_t)__popcll(lm & below);
+    if ((ll >> lane) & 1ull) pos = n_quad + (wave ? l0 : 0u) + (uint32_t)__popcll(ll & below);
+    if (wave < 2u && pos < RCAP) s_rec[pos] = mine;
+    __syncthreads();
+    return min(n_quad + l0 + l1, RCAP);
+}
+
 // Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW (<= 256 segments) with the
 // exact range of this cell's sample rows that accept each (fr_records.hpp), compacted into s_rec (<= RCAP kept), and
 // the padded table of the strip's exact sample abscissae.  Two workgroup barriers.  -> number of records.
@@ -184,6 +245,8 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
 {
     if (NW == 4u && 2u * nseg <= 64u)                                        // (workgroup-uniform; s_tmp: 1 KB, free until the bands start)
         return c4_setup_small<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
+    if (NW == 4u && 2u * nseg <= 128u)
+        return c4_setup_mid<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
     constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
