@@ -4,11 +4,12 @@
 //
 // Same integers as glyphWindingAt per pixel (:35-73): winding(x) = sum over accepted roots of step [x < J].
 // With one sample per pixel there is no inside/outside rule to apply per sample row, so nothing has to be sorted:
-// every crossing adds its step to ONE byte of a row of winding DIFFERENCES (LDS, ds_add_u32 on the dword holding
-// it) straight from the evaluation — d[J - 1] += step, w(x) = sum over i >= x of d[i] — and a window lane
-// integrates 16 pixels exactly as cov4_kernel integrates coverage (multiply by 0x01010101 per dword, 3-step chain,
-// 4-step DPP scan across the 16 windows of a row).  The row is stored right to left (byte q = NCOL - 1 - x) so the
-// suffix sum is a prefix sum; a lane reverses its 16 bytes before the store.  Bytes carry a bias (32 in LDS, 96
+// every crossing subtracts its step from ONE byte of a row of winding DIFFERENCES (LDS, ds_add_u32 on the dword
+// holding it) straight from the evaluation — w(x) = w(0) - sum over the crossings with J <= x of their step, byte J
+// takes - step, and w(0) = the sum of all steps rides in the high half of the row's crossing counter (one more
+// ds_add_u32 that the count needs anyway) — and a window lane integrates 16 pixels exactly as cov4_kernel
+// integrates coverage (multiply by 0x01010101 per dword, 3-step chain, 4-step DPP scan across the 16 windows of a
+// row), in pixel order.  Bytes carry a bias (32 in LDS, 96
 // after the scans) and hold |w| <= 31: a row with more than 31 crossings (it alone could leave that range) takes
 // the direct path — 16-bit differences, suffix scan, pixels written from there.  No lists, no sort, no toggles:
 // per 4 KB of gray output about half the vector instructions of cov4_kernel's 16-sample pixel.
@@ -189,10 +190,11 @@ void win1_kernel(const RenderArgs A)
                             }
                         }
                         if (livep & (J > 0)) {
-                            // d[J - 1] += step, stored right to left: byte q = NCOL - J of the row
-                            const uint32_t q = NCOL - (uint32_t)J;
-                            atomicAdd(reinterpret_cast<uint32_t *>(s_E + row * L::EROW + (q & ~3u)), (code - 1u) << (8u * (q & 3u)));
-                            atomicAdd(&s_cnt[row], 1u);
+                            // w(x) = w(0) - sum of the steps of the crossings with J <= x: byte J of the row takes - step
+                            // (J = NCOL lands in the row's pad), the row's counter word the step (high half: w(0)) and the count
+                            const uint32_t q = (uint32_t)J;
+                            atomicAdd(reinterpret_cast<uint32_t *>(s_E + row * L::EROW + (q & ~3u)), (1u - code) << (8u * (q & 3u)));
+                            atomicAdd(&s_cnt[row], 1u + ((code - 1u) << 16));
                         }
                     }
                     k_cur = max(s_next, carry);
@@ -203,7 +205,7 @@ void win1_kernel(const RenderArgs A)
             rr0 += span;
         }
         c4_wave_lds_sync();
-        const uint32_t cnt = s_cnt[lane & 15u];
+        const uint32_t cnt = s_cnt[lane & 15u] & 0xffffu;
         unsigned char *const out_band = reinterpret_cast<unsigned char *>(A.out) +
                                         (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
         const size_t row_bytes = (size_t)A.out_stride * ESZ;
@@ -282,7 +284,7 @@ void win1_kernel(const RenderArgs A)
             }
         }
 
-        // ---- windows: lane = 16 pixels of one pixel row (right to left in LDS); integrate, map, store
+        // ---- windows: lane = 16 pixels of one pixel row; integrate, map, store
         constexpr uint32_t K1 = 0x01010101u;
 #pragma unroll
         for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) {
@@ -307,14 +309,13 @@ void win1_kernel(const RenderArgs A)
                 s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
                 s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u;
             }
-            const uint32_t cin = inc - T + 32u;                             // winding entering my window, + 32: in [1, 63]
+            const int w0 = (int)s_cnt[prow] >> 16;                           // w(0) of my pixel row
+            const uint32_t cin = inc - T + 32u + (uint32_t)w0;              // winding entering my window, + 32: in [1, 63]
             const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
             x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 96 + w
-            // back to pixel order: byte q of the row holds pixel NCOL - 1 - q
-            const uint32_t p0 = __builtin_amdgcn_perm(x3, x3, 0x00010203u), p1 = __builtin_amdgcn_perm(x2, x2, 0x00010203u);
-            const uint32_t p2 = __builtin_amdgcn_perm(x1, x1, 0x00010203u), p3 = __builtin_amdgcn_perm(x0, x0, 0x00010203u);
+            const uint32_t p0 = x0, p1 = x1, p2 = x2, p3 = x3;              // (pixel order: byte x of the row is pixel x)
             if ((ovf_rows >> prow) & 1u) continue;                          // stored by the direct path above
-            unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(NCOL - 16u - 16u * wx) * ESZ;
+            unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
             if (MODE == MODE1_MASK) {
                 auto m4 = [](uint32_t x) -> uint32_t {
                     const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
