@@ -211,6 +211,20 @@ def test_win1_kernel_matches_the_oracle(ctx, oracle, mode, omode):
         gl.append(Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs]))
     parts = [synth_glyphset(3, 128, first_index=61), stroke_glyphset(3, 160, first_index=62), synth_glyphset(2, 250, first_index=63)]
     gl += [p.glyph(i) for p in parts for i in range(len(p))]
+    # ten nested squares of one orientation, both ways round: windings up to +10 and down to -10 — both clamps of the
+    # gray map (render_glyph.zig:28: w >= 8 -> 255, w <= -5 -> 0), i.e. the map's general path
+    for flip in (False, True):
+        cs = []
+        for k in range(10):
+            a, b = 100 + 90 * k, 1900 - 90 * k
+            poly = np.array([(a, a), (a, b), (b, b), (b, a)][::-1 if flip else 1], np.int64)
+            nxt = np.roll(poly, -1, 0)
+            pts = np.empty((9, 2), np.int64)
+            pts[0:-1:2] = poly
+            pts[1:-1:2] = np.trunc((poly + nxt) / 2)
+            pts[-1] = poly[0]
+            cs.append(Contour(pts.astype(np.int16)))
+        gl.append(Glyph(Box(100, 100, 1900, 1900), cs))
     gs = GlyphSet(gl)
     dt = np.int16 if mode == fr.FR_WINDING_I16 else np.uint8
     for cell, center in ((256, False), (128, True)):
@@ -233,7 +247,9 @@ def test_win1_kernel_matches_the_oracle(ctx, oracle, mode, omode):
                 ctx.set_option("cov4", 1); ctx.set_option("min_wgs", 2048)
             assert np.array_equal(got, ref), (cell, opts)
     if mode == fr.FR_WINDING_I16:
-        assert ref.max() >= 2 and ref.min() < 0
+        assert ref.max() == 10 and ref.min() == -10
+    if mode == fr.FR_GRAY_DEBUG:
+        assert ref.max() == 255 and ref.min() == 0
     # a 512 x 48 cell: two 256-pixel strips, three bands of 16 rows
     sg = synth_glyphset(2, 64, first_index=880)
     rows = [(i, int(np.floor(sg.boxes[i][0] * 0.25)), int(np.ceil(sg.boxes[i][3] * 0.25)) - 200, 512, 48, 0, 48 * i, np.float32(0.25)) for i in range(2)]
