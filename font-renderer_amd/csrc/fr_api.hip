@@ -438,9 +438,10 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
             const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
             const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= max_h_fast &&
                               nsg <= fr::cov4_max_segments();
-            if (fast && gs->h_root_bound[jb.glyph] <= 128u) order[n_fast++] = j;
-            else if (fast && gs->h_root_bound[jb.glyph] <= 256u) mid256.push_back(j);
-            else if (fast) mid.push_back(j);           // (<= 256 segments: <= 512 candidate roots)
+            const uint32_t rb = gs->h_root_bound[jb.glyph];
+            if (fast && nsg <= 256u && rb <= 128u) order[n_fast++] = j;
+            else if (fast && nsg <= 256u && rb <= 256u) mid256.push_back(j);
+            else if (fast && rb <= 512u) mid.push_back(j);     // (<= 384 segments, <= 512 roots the vertex rule cannot discard)
             else slow.push_back(j);
         }
         p->n_fast128 = n_fast;
@@ -555,12 +556,17 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.bands_per_wg = bpw;
         a.band_groups = (bands + bpw - 1) / bpw;
     };
-    // A mixed plan: the jobs of the general kernel (a real font's few glyphs of more than 256 segments) are a short
-    // kernel with a long critical path — forked onto a second stream so that it runs beside the cov4 / win1 part
-    // instead of after it (the jobs' cells are disjoint); joined before anything else touches the output.
+    // A mixed plan: the smaller launches (a real font's few glyphs of many segments: the 512-record instance, the
+    // general kernel) are short kernels with long critical paths — forked onto a second stream so that they run beside
+    // the large one instead of before / after it (the jobs' cells are disjoint); joined before anything else touches the
+    // output.
     fr_ctx *const ctx = plan->ctx;
     hipStream_t gst = ctx->stream;
-    const bool forked = ctx->overlap && n_fast && n_gen;
+    const uint32_t part_cnt[3] = {plan->n_fast128, plan->n_fast256 - plan->n_fast128, n_fast - plan->n_fast256};
+    const int big = part_cnt[0] >= part_cnt[1] ? (part_cnt[0] >= part_cnt[2] ? 0 : 2) : (part_cnt[1] >= part_cnt[2] ? 1 : 2);
+    const int n_launches = (n_gen ? 1 : 0) + (part_cnt[0] ? 1 : 0) + (part_cnt[1] ? 1 : 0) + (part_cnt[2] ? 1 : 0);
+    // (the largest fast part stays on the context's stream; every other launch of the plan goes beside it)
+    const bool forked = ctx->overlap && n_fast && n_launches > 1;
     if (forked) {
         if (!ctx->aux) {
             HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -603,8 +609,9 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.n_jobs = cnt; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
         split_bands(fr::cov4_wg_waves(), cnt, plan->fast_bands, plan->fast_strips);
         const int pm = plan->params.mode;
-        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, rec_cap, plan->ctx->stream));
-        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), rec_cap, plan->ctx->stream));
+        hipStream_t pst = (forked && part != big) ? ctx->aux : ctx->stream;
+        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, rec_cap, pst));
+        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), rec_cap, pst));
     }
     return FR_OK;
     };

@@ -235,7 +235,7 @@ __device__ __forceinline__ uint32_t c4_setup_mid(const RenderArgs &A, const Job 
     return min(n_quad + l0 + l1, RCAP);
 }
 
-// Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW (<= 256 segments) with the
+// Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW, ... (<= 256 segments; <= 384 where RCAP = 512) with the
 // exact range of this cell's sample rows that accept each (fr_records.hpp), compacted into s_rec (<= RCAP kept), and
 // the padded table of the strip's exact sample abscissae.  Two workgroup barriers.  -> number of records.
 // N: samples per pixel axis (4: cov4_kernel, 1: win1_kernel); NCOL: sample columns of the strip.
@@ -249,7 +249,8 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
         return c4_setup_mid<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
-    constexpr uint32_t CPT = 512u / (64u * NW);                             // candidates per thread
+    constexpr uint32_t CPT = (RCAP >= 512u ? 768u : 512u) / (64u * NW);     // candidates per thread (<= 384 segments where 512 records are kept, else <= 256)
+    s_wcnt = s_tmp;                                                          // (2 CPT NW counters: the scratch block has the room)
     Rec40 mine[CPT];
     unsigned long long lm[CPT], ll[CPT];
 #pragma unroll

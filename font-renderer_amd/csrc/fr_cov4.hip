@@ -576,7 +576,7 @@ extern "C" int fr_debug_read_c4_stats(unsigned long long *out16, int reset)
 }
 #endif
 uint32_t cov4_wg_waves() { return C4_WAVES; }
-uint32_t cov4_max_segments() { return 256u; }
+uint32_t cov4_max_segments() { return 384u; }     // (with 512 record slots; 256 for the smaller instances: fr_plan_create)
 
 template <int WLOG, int RPL>
 static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
