@@ -11,7 +11,7 @@
 // a "fast class" (VOP2 add/sub/and/or/xor/lshrrev/mov on VGPRs or literals, v_add_f32 / v_sub_f32 /
 // v_mul_f32) that takes ~2 — but only with an EVEN number of waves per SIMD (at 3 waves/SIMD they cost
 // 1.8x); v_sqrt_f32 ~7; a VOP2 v_cndmask whose VCC was not written by the instruction right before it
-// ~10-19.  So this kernel (1) runs 8-wave workgroups, two per CU = 4 waves per SIMD; (2) turns the
+// ~10-19.  So this kernel (1) runs 4-wave workgroups, four per CU = 4 waves per SIMD; (2) turns the
 // inside masks + transpose + popcount of the general kernel into signed byte DIFFERENCES of coverage that
 // the window lanes integrate with a handful of fast adds (below); (3) keeps selects next to their compares
 // or on SGPR masks; (4) drops work whose result is already known (the acceptance tests inside an exact
@@ -96,10 +96,10 @@ struct C4Lds {
     static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
 };
 
-// One workgroup (8 waves) = one cell (or one group of its wave bands, or one 256-px strip of it).
+// One workgroup (4 waves) = one cell (or one group of its wave bands, or one 256-px strip of it).
 // WLOG: strip width 16 << WLOG pixels (3: 128, 4: 256).  CAP: crossings a sample row keeps (8 / 16 / 32);
-// fuller rows take the direct sum over the glyph's records.  RPL: root records per lane, 4 or 8 — a workgroup
-// keeps up to 64 RPL records in LDS (256: four workgroups per CU; 512: three).
+// fuller rows take the direct sum over the glyph's records.  RPL: root records per lane, 2, 4 or 8 — a workgroup
+// keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).
 template <int WLOG, int CAP, int RPL>
 __global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
 void cov4_kernel(const RenderArgs A)
