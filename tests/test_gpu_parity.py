@@ -140,7 +140,7 @@ def _render_opt(ctx, gs, jobs, shape, n, center, **opts):
 
 @pytest.mark.parametrize("cell,segs,center", [(256, 128, True), (256, 128, False), (128, 32, True), (128, 200, False), (256, 250, True)])
 def test_cov4_kernel_matches_the_oracle(ctx, oracle, cell, segs, center):
-    """cov4_kernel (fr_cov4.hip: coverage by integrating signed byte differences, 8-wave workgroups) on the
+    """cov4_kernel (fr_cov4.hip: coverage by integrating signed byte differences, 4-wave workgroups) on the
     shapes it takes — 256- and 128-pixel cells, 16 samples per pixel, up to 256 segments — against the
     oracle, and byte-identical to the general kernel on the same plan (ctx option cov4 = 0)."""
     n_g = 6
