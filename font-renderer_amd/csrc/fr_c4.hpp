@@ -96,6 +96,16 @@ __device__ __forceinline__ void c4_wave_lds_sync()
 }
 
 
+// 16-byte streaming store of finished pixels (never read again by this kernel): the non-temporal hint keeps them from
+// displacing the tables the kernel does re-read in L2
+__device__ __forceinline__ void c4_store16(void *dst, uint4 v)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 u32x4_u __attribute__((aligned(4)));
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_u *>(dst));
+}
+
 // a settled candidate as the kernels keep it (40 bytes): row range [ra, re) in the low bits of `fr`
 __device__ __forceinline__ Rec40 c4_make_rec40(const Rec &r, uint32_t ra, uint32_t re)
 {

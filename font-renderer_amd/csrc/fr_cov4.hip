@@ -333,7 +333,7 @@ void cov4_kernel(const RenderArgs A)
             // no crossing on any of my 64 sample rows: every winding is 0 — store the band's background
             for (uint32_t yl = lane >> WLOG; yl < 16u; yl += (64u >> WLOG)) {
                 const uint4 z = make_uint4(0, 0, 0, 0);
-                __builtin_memcpy(out_band + (size_t)yl * A.out_stride + 16u * wx, &z, 16);
+                c4_store16(out_band + (size_t)yl * A.out_stride + 16u * wx, z);
             }
             c4_wave_lds_sync();
             continue;
@@ -552,7 +552,7 @@ void cov4_kernel(const RenderArgs A)
                 return r;
             };
             const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
-            __builtin_memcpy(out_band + (size_t)prow * A.out_stride + 16u * wx, &v, 16);
+            c4_store16(out_band + (size_t)prow * A.out_stride + 16u * wx, v);
         }
         c4_wave_lds_sync();                        // E is the next band's list region
     }

@@ -215,8 +215,8 @@ void win1_kernel(const RenderArgs A)
             const uint4 v = make_uint4(bg, bg, bg, bg);
             for (uint32_t yl = lane >> WLOG; yl < W1_ROWS; yl += (64u >> WLOG)) {
                 unsigned char *dst = out_band + (size_t)yl * row_bytes + 16u * ESZ * wx;
-                __builtin_memcpy(dst, &v, 16);
-                if (ESZ == 2u) __builtin_memcpy(dst + 16, &v, 16);
+                if (ESZ == 2u) { __builtin_memcpy(dst, &v, 16); __builtin_memcpy(dst + 16, &v, 16); }
+                else c4_store16(dst, v);
             }
             c4_wave_lds_sync();
             continue;
@@ -323,7 +323,7 @@ void win1_kernel(const RenderArgs A)
                     return nz | (nz - (nz >> 7));                           // 0x80 -> 0xff
                 };
                 const uint4 v = make_uint4(m4(p0), m4(p1), m4(p2), m4(p3));
-                __builtin_memcpy(dst, &v, 16);
+                c4_store16(dst, v);
             } else if (MODE == MODE1_GRAY_DEBUG) {
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 auto g2 = [](uint32_t h) -> uint32_t {                      // two 16-bit lanes holding 96 + w
@@ -342,7 +342,7 @@ void win1_kernel(const RenderArgs A)
                 uint4 v;
                 if (__builtin_expect(__ballot(!plain) == 0ull, 1)) v = make_uint4(y0 * 20u, y1 * 20u, y2 * 20u, y3 * 20u);
                 else v = make_uint4(g4(p0), g4(p1), g4(p2), g4(p3));
-                __builtin_memcpy(dst, &v, 16);
+                c4_store16(dst, v);
             } else {
                 typedef short i16x2 __attribute__((ext_vector_type(2)));
                 auto w2 = [](uint32_t h) -> uint32_t {
@@ -358,6 +358,8 @@ void win1_kernel(const RenderArgs A)
                     o[2 * q + 1] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
                 }
                 const uint4 va = make_uint4(o[0], o[1], o[2], o[3]), vb = make_uint4(o[4], o[5], o[6], o[7]);
+                // (two plain stores: each covers every other 16 bytes of the row, which the streaming hint would send to
+                // memory as half-written sectors — measured 2.6 x slower)
                 __builtin_memcpy(dst, &va, 16);
                 __builtin_memcpy(dst + 16, &vb, 16);
             }
