@@ -128,12 +128,12 @@ __device__ __forceinline__ Rec40 c4_make_rec40(const Rec &r, uint32_t ra, uint32
 // which record_settle's walks would not move — and walks as before otherwise.  Same records, same order.
 template <uint32_t RCAP, int N, uint32_t NCOL>
 __device__ __forceinline__ uint32_t c4_setup_small(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
-                                                   int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
+                                                   int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp, const float *cyt = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
     RowGeom geo;
-    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase; geo.cyt = cyt;
     const bool have = lane < 2u * nseg;
     Rec r;
     RowGuess g;
@@ -189,13 +189,13 @@ __device__ __forceinline__ uint32_t c4_setup_small(const RenderArgs &A, const Jo
 // (h = 0) take the guess when all four classes confirm it and walk otherwise.
 template <uint32_t RCAP, int N, uint32_t NCOL>
 __device__ __forceinline__ uint32_t c4_setup_mid(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
-                                                 int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
+                                                 int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp, const float *cyt = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t c = tid & 127u, h = tid >> 7;
     const uint32_t Hs = job.h * (uint32_t)N;
     RowGeom geo;
-    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase; geo.cyt = cyt;
     const bool have = c < 2u * nseg;
     Rec r;
     RowGuess g;
@@ -251,12 +251,12 @@ __device__ __forceinline__ uint32_t c4_setup_mid(const RenderArgs &A, const Job 
 // N: samples per pixel axis (4: cov4_kernel, 1: win1_kernel); NCOL: sample columns of the strip.
 template <uint32_t NW, uint32_t RCAP, int N, uint32_t NCOL>
 __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, uint32_t x0s,
-                                             int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp)
+                                             int phase, float *s_cxp, Rec40 *s_rec, uint32_t *s_wcnt, uint32_t *s_tmp, const float *cyt = nullptr)
 {
     if (NW == 4u && 2u * nseg <= 64u)                                        // (workgroup-uniform; s_tmp: 1 KB, free until the bands start)
-        return c4_setup_small<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
+        return c4_setup_small<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp, cyt);
     if (NW == 4u && 2u * nseg <= 128u)
-        return c4_setup_mid<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp);
+        return c4_setup_mid<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp, cyt);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
     constexpr uint32_t CPT = (RCAP >= 512u ? 768u : 512u) / (64u * NW);     // candidates per thread (<= 384 segments where 512 records are kept, else <= 256)
@@ -273,7 +273,7 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
         if (c < 2u * nseg) {
             Rec r;
             RowGeom geo;
-            geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase;
+            geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = Hs; geo.n = N; geo.phase = phase; geo.cyt = cyt;
             build_record_rows(A.seg_pts + 6u * (size_t)(seg0 + (c >> 1)), c & 1u, geo, r);
             const uint32_t ra = __builtin_bit_cast(uint32_t, r.lo), re = __builtin_bit_cast(uint32_t, r.hi);
             live = ra < re;

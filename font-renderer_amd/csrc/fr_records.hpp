@@ -161,8 +161,10 @@ struct RowGeom {
     float scale;
     uint32_t rows;       // sample rows of the cell (h * N)
     int n, phase;
+    const float *cyt = nullptr;   // optional: the ray heights of all the cell's rows, computed once by this very expression
     __device__ __forceinline__ float cy(uint32_t r) const
     {
+        if (cyt) return cyt[r];
         return ((float)(max_y - (int32_t)(r / (uint32_t)n)) - sub_off((int)(r % (uint32_t)n), n, phase)) / scale;
     }
     // fractional row index at which the ray height equals c (rows r >= x lie at or below c)

@@ -37,7 +37,8 @@ struct W1Lds {
     static constexpr uint32_t WAVE = (OFF_ROFF + RCAP * 2u + 15u) & ~15u;
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
-    static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
+    static constexpr uint32_t OFF_CYT = OFF_WCNT + 64u;                     // ray heights of the cell's rows (cells of <= 256 rows)
+    static constexpr uint32_t TOTAL = OFF_CYT + 1024u;
 };
 
 __device__ __forceinline__ uint32_t w1_gray(int w)
@@ -77,10 +78,19 @@ void win1_kernel(const RenderArgs A)
     unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
 
-    const uint32_t rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
+    const float soff = phase ? 0.5f : 0.0f;
+    // cells of up to 256 rows: every row's ray height cy = (f32(max_y - y) - off) / scale (:27) is computed once — the
+    // set-up looks at four rows per candidate and every band at 16, each of them a division otherwise
+    const float *cyt = nullptr;
+    if (job.h <= 256u) {                                                    // (workgroup-uniform)
+        float *t = reinterpret_cast<float *>(smem + L::OFF_CYT);
+        if (tid < job.h) t[tid] = ((float)(job.max_y - (int32_t)tid) - soff) / job.scale;
+        __syncthreads();
+        cyt = t;
+    }
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES), cyt);
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale;
-    const float soff = phase ? 0.5f : 0.0f;
     const float joff = (float)min_xs + soff - 1.0f;
     const float ncolf = (float)NCOL;
     const bool few = RPL == 2 || rec_cnt <= 128u;   // (RPL == 2: the plan sends only glyphs of <= 128 candidate roots)
@@ -107,7 +117,7 @@ void win1_kernel(const RenderArgs A)
         if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
         const uint32_t y0 = band * W1_ROWS;         // first pixel row = first sample row of my band
         // ray height of row `lane & 15`: cy = (f32(max_y - y) - off) / scale   (:27)
-        const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane & 15u))) - soff) / job.scale;
+        const float cy = cyt ? cyt[y0 + (lane & 15u)] : ((float)(job.max_y - (int32_t)(y0 + (lane & 15u))) - soff) / job.scale;
         {
             uint4 *z = reinterpret_cast<uint4 *>(s_E);
             const uint4 bias = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
