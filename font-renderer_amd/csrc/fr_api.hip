@@ -127,7 +127,7 @@ extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_last_error(void) { return g_err; }
-const char *fr_build_id(void) { return "r02.12"; }
+const char *fr_build_id(void) { return "r02.13"; }
 
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
 {
