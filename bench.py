@@ -189,13 +189,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)                                       # HIP events on the LAUNCH stream around the K back-to-back launches
     for _ in range(args.steps):
         step()
+    ev1.record(stream)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1) / args.steps              # average launch duration over the timed region (sustained: back to back)
     tot_pixels = pixels
     if world > 1:
         dev = "cuda" if backend == "nccl" else "cpu"
@@ -231,7 +235,11 @@ def main():
         except Exception as e:                               # the optional assembly must never cost the throughput line
             gather = {"error": f"{type(e).__name__}: {e}"}
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream, the render alone
+    # ---- roofline of the dominant kernel: its launch duration, HIP events on the launch stream around each launch
+    # (fr_plan_render_timed) — what rocprofv3 --kernel-trace reports for the kernel (profiles/r02/*_kernel_stats.csv).
+    # Beside it the launch PERIOD of the timed region (the events above / steps): back to back, a kernel that writes
+    # > 4 TB/s is followed by up to 35 us in which the memory side drains before the next one starts; that is in
+    # `value` / `ms_per_step` and in `period_ms` / `frac_of_period` here, not in the kernel's own duration.
     kms = sorted(plan.render_timed(out.data_ptr(), W, H) for _ in range(max(5, min(args.steps, 20))))
     k_ms = float(np.mean(kms))
     achieved = pixels * bpp / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel; 2 for int16 windings)
@@ -257,7 +265,10 @@ def main():
         kname = f"fr::{'cov4' if n == 4 else 'win1'}_kernel ({pstats['jobs_cov4']} jobs) + fr::render_kernel ({pstats['jobs_general']} jobs)"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": pixels * bpp, "kernel_ms": round(k_ms, 4), "build_id": fr.build_id()}
+                "algorithmic_bytes_per_launch": pixels * bpp, "kernel_ms": round(k_ms, 4), "period_ms": round(float(gpu_ms), 4),
+                "frac_of_period": round(pixels * bpp / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "timing": "kernel_ms: HIP events around each launch (== rocprofv3 kernel duration); period_ms: HIP events around the timed region's back-to-back launches / steps",
+                "build_id": fr.build_id()}
 
     # ---- configs[0]: the reference's own call shape — one glyph, one image (STIX 'A' at 64 -> 47 x 45), latency per call
     c1 = None

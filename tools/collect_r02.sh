@@ -22,7 +22,7 @@ echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
 for w in c3_cjk21k_256px_s128_16spp c3_cjk21k_256px_s256_16spp c3_strokes21k_256px_s128_16spp real_dejavuserif_italic_whole_font_256px_16spp \
          c4_bmp_shard_128px_s32_16spp c2_ascii95_128px_s32_16spp c5_sdf_shard_512px_s64 c3_cjk21k_256px_s128_gray_debug c3_cjk21k_256px_s128_winding_i16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 200 --warmup 100 --no-cpu-baseline > /dev/null 2>&1
   cp $out/kt_$w/kt_kernel_stats.csv $out/${w}_kernel_stats.csv 2>/dev/null
   echo "kt $w done"
 done
