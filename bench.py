@@ -237,9 +237,10 @@ def main():
 
     # ---- roofline of the dominant kernel: its launch duration, HIP events on the launch stream around each launch
     # (fr_plan_render_timed) — what rocprofv3 --kernel-trace reports for the kernel (profiles/r02/*_kernel_stats.csv).
-    # Beside it the launch PERIOD of the timed region (the events above / steps): back to back, a kernel that writes
-    # > 4 TB/s is followed by up to 35 us in which the memory side drains before the next one starts; that is in
-    # `value` / `ms_per_step` and in `period_ms` / `frac_of_period` here, not in the kernel's own duration.
+    # Beside it the launch PERIOD of the timed region (the events above / steps).  For the fast kernels the un-profiled
+    # back-to-back loop runs up to 11 % slower than the kernel's duration (under rocprofv3 --kernel-trace the same loop has
+    # no gaps and period == duration: DESIGN.md section 7); that is in `value` / `ms_per_step` and in `period_ms` /
+    # `frac_of_period` here, not in the kernel's own duration.
     kms = sorted(plan.render_timed(out.data_ptr(), W, H) for _ in range(max(5, min(args.steps, 20))))
     k_ms = float(np.mean(kms))
     achieved = pixels * bpp / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel; 2 for int16 windings)
