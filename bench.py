@@ -84,7 +84,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=100, help="untimed steps first (the GPU clocks take ~100 launches to come up: fewer makes the timed region up to 11 %% slower than the kernel)")
     ap.add_argument("--workload", default="c3_cjk21k_256px_s128_16spp", choices=sorted(WORKLOADS))
     ap.add_argument("--glyphs", type=int, default=0, help="override the per-GPU glyph count (smoke runs)")
     ap.add_argument("--total-glyphs", type=int, default=0, help="strong scaling: the whole job's glyph count, sharded over the ranks")
@@ -237,10 +237,8 @@ def main():
 
     # ---- roofline of the dominant kernel: its launch duration, HIP events on the launch stream around each launch
     # (fr_plan_render_timed) — what rocprofv3 --kernel-trace reports for the kernel (profiles/r02/*_kernel_stats.csv).
-    # Beside it the launch PERIOD of the timed region (the events above / steps).  For the fast kernels the un-profiled
-    # back-to-back loop runs up to 11 % slower than the kernel's duration (under rocprofv3 --kernel-trace the same loop has
-    # no gaps and period == duration: DESIGN.md section 7); that is in `value` / `ms_per_step` and in `period_ms` /
-    # `frac_of_period` here, not in the kernel's own duration.
+    # Beside it the launch PERIOD of the timed region (the events above / steps): the same number once the clocks are up
+    # (they take ~100 launches: with --warmup 5 a 0.29 ms kernel ran at a period of 0.32 ms).
     kms = sorted(plan.render_timed(out.data_ptr(), W, H) for _ in range(max(5, min(args.steps, 20))))
     k_ms = float(np.mean(kms))
     achieved = pixels * bpp / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel; 2 for int16 windings)

@@ -6,16 +6,16 @@ tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-python3 bench.py > $out/c3_bench.json 2> $out/c3_bench.err || exit 1
+python3 bench.py --steps 200 > $out/c3_bench.json 2> $out/c3_bench.err || exit 1
 echo "c3 done"
 for w in c3_cjk21k_256px_s256_16spp c3_cjk21k_256px_s64_16spp c3_cjk21k_256px_s32_16spp c3_cjk21k_256px_s16_16spp c3_strokes21k_256px_s128_16spp \
          real_dejavuserif_italic_whole_font_256px_16spp c4_bmp_shard_128px_s32_16spp c3_cjk21k_256px_s128_gray_debug c3_cjk21k_256px_s128_winding_i16; do
-  python3 bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > $out/${w}_bench.json 2>/dev/null
+  python3 bench.py --workload $w --steps 200 --warmup 100 --no-cpu-baseline > $out/${w}_bench.json 2>/dev/null
   echo "$w done"
 done
-python3 bench.py --workload c2_ascii95_128px_s32_16spp --steps 500 --warmup 20 --no-cpu-baseline > $out/c2_ascii95_128px_s32_16spp_bench.json 2>/dev/null
-python3 bench.py --workload c2_ascii95_real_128px_16spp --steps 500 --warmup 20 --cpu-seconds 4 > $out/c2_ascii95_real_128px_16spp_bench.json 2>/dev/null
-python3 bench.py --workload c5_sdf_shard_512px_s64 --steps 30 --warmup 3 --cpu-seconds 8 > $out/c5_sdf_shard_512px_s64_bench.json 2>/dev/null
+python3 bench.py --workload c2_ascii95_128px_s32_16spp --steps 2000 --warmup 500 --no-cpu-baseline > $out/c2_ascii95_128px_s32_16spp_bench.json 2>/dev/null
+python3 bench.py --workload c2_ascii95_real_128px_16spp --steps 2000 --warmup 500 --cpu-seconds 4 > $out/c2_ascii95_real_128px_16spp_bench.json 2>/dev/null
+python3 bench.py --workload c5_sdf_shard_512px_s64 --steps 100 --warmup 50 --cpu-seconds 8 > $out/c5_sdf_shard_512px_s64_bench.json 2>/dev/null
 python3 tools/exact_bench.py > $out/exact_lattice.json 2>/dev/null
 python3 tools/c1_latency.py $GRAFT_REPO_ROOT/font-renderer_amd/libfr_raster.so > $out/c1_latency.txt 2>/dev/null
 echo "bench lines done"
