@@ -98,6 +98,7 @@ struct fr_glyphset {
     fr::Rec *d_recs = nullptr;
     std::vector<uint32_t> h_glyph_seg_start;    // host copy: plans attach each job's segment range to it
     std::vector<uint32_t> h_root_bound;         // per glyph: candidate roots the vertex rule cannot discard (>= live records)
+    std::vector<uint32_t> h_ray_bound;          // per glyph: estimated maximum of the crossings of one horizontal ray
 };
 
 struct fr_plan {
@@ -127,7 +128,7 @@ extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_last_error(void) { return g_err; }
-const char *fr_build_id(void) { return "r02.13"; }
+const char *fr_build_id(void) { return "r02.14"; }
 
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
 {
@@ -290,6 +291,36 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
         }
         root_bound[g] = nb;
     }
+    // Estimate of the most crossings one horizontal ray can have with a glyph: a sweep over the segments' y extents
+    // (the control points bound the curve), counted once between the heights of its ends and twice where it overshoots
+    // them.  Glyphs
+    // that stay at or under 16 take the instance that keeps 16 crossings per sample row in registers (fr_plan_create).
+    std::vector<uint32_t> ray_bound(n_glyphs, 0u);
+    {
+        std::vector<std::pair<int32_t, int32_t>> ev;     // (2 y + [closing], +-weight): openings sort before closings at one y
+        for (uint32_t g = 0; g < n_glyphs; ++g) {
+            ev.clear();
+            for (uint32_t sgi = gseg[g]; sgi < gseg[g + 1]; ++sgi) {
+                const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
+                const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
+                // between the heights of its two ends a quadratic is met once; where it overshoots them (towards the
+                // control point: the vertex lies inside) twice, and not at all between the ends' heights on that side
+                const int32_t clo = std::min(p0y, p2y), chi = std::max(p0y, p2y);
+                // (half-open at the ends' heights, as the reference's own t in [0, 1) is: two segments that meet at a
+                // vertex are not both counted there.  An estimate that steers jobs, not a proof: a row that does hold
+                // more than the instance keeps takes the exact direct sum)
+                ev.emplace_back(2 * clo, 1);
+                ev.emplace_back(2 * chi, -1);
+                // (the vertex overshoots the nearer end by at most half of what the control point does)
+                if (p1y > chi) { ev.emplace_back(2 * chi, 2); ev.emplace_back(2 * (chi + (p1y - chi + 1) / 2) + 1, -2); }
+                if (p1y < clo) { ev.emplace_back(2 * (clo - (clo - p1y + 1) / 2), 2); ev.emplace_back(2 * clo, -2); }
+            }
+            std::sort(ev.begin(), ev.end());
+            int32_t cur = 0, best = 0;
+            for (const auto &e : ev) { cur += e.second; best = std::max(best, cur); }
+            ray_bound[g] = (uint32_t)best;
+        }
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     fr_glyphset *gs = new (std::nothrow) fr_glyphset;
     if (!gs) return fail(FR_E_NOMEM, "fr_glyphset_create: host allocation");
@@ -324,6 +355,7 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     GS_TRY(hipMemcpyAsync(gs->d_glyph_seg_start, gseg.data(), ((size_t)n_glyphs + 1) * 4, hipMemcpyHostToDevice, st));
     gs->h_glyph_seg_start = gseg;
     gs->h_root_bound = root_bound;
+    gs->h_ray_bound = ray_bound;
     GS_TRY(hipMemsetAsync(gs->d_rec_count, 0, ((size_t)n_glyphs + 1) * 4, st));
     fr::launch_prepare(gs->d_pts, gs->d_seg_p0, gs->d_glyph_seg_start, nullptr, n_glyphs, gs->d_recs,
                        gs->d_rec_count, st);
@@ -439,7 +471,8 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
             const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= max_h_fast &&
                               nsg <= fr::cov4_max_segments();
             const uint32_t rb = gs->h_root_bound[jb.glyph];
-            if (fast && nsg <= 256u && rb <= 128u) order[n_fast++] = j;
+            // (the 128-record instance keeps 16 crossings per sample row: glyphs whose rays can meet more go one tier up)
+            if (fast && nsg <= 256u && rb <= 128u && gs->h_ray_bound[jb.glyph] <= 16u) order[n_fast++] = j;
             else if (fast && nsg <= 256u && rb <= 256u) mid256.push_back(j);
             else if (fast && rb <= 512u) mid.push_back(j);     // (<= 384 segments, <= 512 roots the vertex rule cannot discard)
             else slow.push_back(j);
