@@ -51,6 +51,8 @@ WORKLOADS = {
     # the reference's own products (one sample per pixel, the pixel corner): renderGlyph's value map, Image.Winding
     "c3_cjk21k_256px_s128_gray_debug": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="gray_debug"),
     "c3_cjk21k_256px_s128_winding_i16": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="winding_i16"),
+    # the reference's own product on the real font: renderGlyph's gray map of every DejaVuSerif-Italic glyph, 6 sizes
+    "real_dejavuserif_italic_whole_font_256px_gray_debug": dict(glyphs=0, cell=256, segs=0, n=1, cols=64, gen="font", font=DEJAVU, mode="gray_debug"),
 }
 
 

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 200 > $out/c3_bench.json 2> $out/c3_bench.err || exit 1
 echo "c3 done"
 for w in c3_cjk21k_256px_s256_16spp c3_cjk21k_256px_s64_16spp c3_cjk21k_256px_s32_16spp c3_cjk21k_256px_s16_16spp c3_strokes21k_256px_s128_16spp \
-         real_dejavuserif_italic_whole_font_256px_16spp c4_bmp_shard_128px_s32_16spp c3_cjk21k_256px_s128_gray_debug c3_cjk21k_256px_s128_winding_i16; do
+         real_dejavuserif_italic_whole_font_256px_16spp real_dejavuserif_italic_whole_font_256px_gray_debug c4_bmp_shard_128px_s32_16spp c3_cjk21k_256px_s128_gray_debug c3_cjk21k_256px_s128_winding_i16; do
   python3 bench.py --workload $w --steps 200 --warmup 100 --no-cpu-baseline > $out/${w}_bench.json 2>/dev/null
   echo "$w done"
 done
@@ -20,7 +20,7 @@ python3 tools/exact_bench.py > $out/exact_lattice.json 2>/dev/null
 python3 tools/c1_latency.py $GRAFT_REPO_ROOT/font-renderer_amd/libfr_raster.so > $out/c1_latency.txt 2>/dev/null
 echo "bench lines done"
 cd /tmp && export TMPDIR=/tmp
-for w in c3_cjk21k_256px_s128_16spp c3_cjk21k_256px_s256_16spp c3_strokes21k_256px_s128_16spp real_dejavuserif_italic_whole_font_256px_16spp \
+for w in c3_cjk21k_256px_s128_16spp c3_cjk21k_256px_s256_16spp c3_strokes21k_256px_s128_16spp real_dejavuserif_italic_whole_font_256px_16spp real_dejavuserif_italic_whole_font_256px_gray_debug \
          c4_bmp_shard_128px_s32_16spp c2_ascii95_128px_s32_16spp c5_sdf_shard_512px_s64 c3_cjk21k_256px_s128_gray_debug c3_cjk21k_256px_s128_winding_i16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --workload $w --steps 200 --warmup 100 --no-cpu-baseline > /dev/null 2>&1
   cp $out/kt_$w/kt_kernel_stats.csv $out/${w}_kernel_stats.csv 2>/dev/null
