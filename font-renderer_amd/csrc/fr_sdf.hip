@@ -122,6 +122,13 @@ __device__ __forceinline__ float obb_gap2(float p0x, float p0y, float tx, float 
 
 // MULTI: some glyph of the batch has more than SDF_BLOCK segments (the minima then wait in 4 KB of LDS between blocks;
 // without them 21 waves fit a CU instead of 13)
+#ifdef FR_SDF_STATS
+__device__ unsigned long long g_sdf_stats[4];    // diagnostic build: distance evaluations (wave level), lanes that wanted them
+extern "C" int fr_debug_read_sdf_stats(unsigned long long *out4)
+{
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sdf_stats), sizeof(g_sdf_stats)) == hipSuccess ? 0 : -2;
+}
+#endif
 template <bool MULTI>
 __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ job_seg,
                                                  const int16_t *__restrict__ seg_pts, uint8_t *__restrict__ out,
@@ -266,6 +273,12 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
                 const float g2 = obb_gap2(e0.x, e0.y, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, qx, qy, slack);
                 const bool active = valid && !(cull && (g2 >= best || g2 > reach2));
                 if (!__any(active)) continue;
+#ifdef FR_SDF_STATS
+                {
+                    const unsigned long long am = __ballot(active);
+                    if (lane == 0) { atomicAdd(&g_sdf_stats[0], 1ull); atomicAdd(&g_sdf_stats[1], (unsigned long long)__popcll(am)); }
+                }
+#endif
 #if defined(FR_SDF_ABLATE) && FR_SDF_ABLATE == 1
                 const float d2 = cull == 7 ? seg_dist2(e, qx, qy) : g2 + 1.0f;                  // timing-only: no distance evaluation
 #else
