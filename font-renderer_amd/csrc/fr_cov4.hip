@@ -583,8 +583,10 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
 {
     const size_t lds = C4Lds<WLOG, RPL>::TOTAL + a.lds_pad;
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        if (lds > 48 * 1024) {                   // (the 512-record instance; below that the default limit is enough)
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
         return hipGetLastError();
     };
