@@ -55,6 +55,7 @@ SYMBOLS = [
     ("fr_plan_render_timed", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     ("fr_plan_pixels", C.c_uint64, [_P]),
     ("fr_plan_stats", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("fr_allgather_bands", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("fr_render_batch", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(RasterParams), _P, C.c_size_t, C.c_size_t]),
     ("fr_render_glyph_dims", C.c_int, [_P, C.c_uint16, C.c_uint16, _P, _P, C.POINTER(C.c_uint16),
                                        C.POINTER(C.c_uint16), C.POINTER(C.c_float)]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <dlfcn.h>
 #include <vector>
 
 namespace fr {
@@ -660,6 +661,37 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.n_jobs = plan->n_jobs;
         HIP_TRY(fr::launch_sdf(a, plan->max_w, plan->max_h, plan->gs->max_seg_per_glyph, (int)plan->ctx->sdf_cull, plan->ctx->stream));
     }
+    return FR_OK;
+}
+
+// ---- optional assembly over RCCL: bound at run time to the RCCL the host already uses (it created the communicator)
+namespace {
+using nccl_allgather_fn = int (*)(const void *, void *, size_t, int /* ncclDataType_t */, void * /* ncclComm_t */, hipStream_t);
+using nccl_rank_fn = int (*)(void *, int *);
+void *rccl_symbol(const char *name)
+{
+    if (void *p = dlsym(RTLD_DEFAULT, name)) return p;
+    for (const char *lib : {"librccl.so", "librccl.so.1"})
+        if (void *h = dlopen(lib, RTLD_NOW | RTLD_NOLOAD))            // only a library that is loaded already
+            if (void *p = dlsym(h, name)) return p;
+    return nullptr;
+}
+}  // namespace
+
+int fr_allgather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes)
+{
+    if (!ctx || !nccl_comm || !atlas_dev) return fail(FR_E_INVALID, "fr_allgather_bands: NULL argument");
+    if (band_bytes == 0) return FR_OK;
+    static const auto all_gather = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
+    static const auto user_rank = reinterpret_cast<nccl_rank_fn>(rccl_symbol("ncclCommUserRank"));
+    if (!all_gather || !user_rank)
+        return fail(FR_E_UNSUPPORTED, "fr_allgather_bands: no RCCL in this process (the host creates the communicator with it)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rank = -1;
+    if (user_rank(nccl_comm, &rank) != 0 || rank < 0) return fail(FR_E_INVALID, "fr_allgather_bands: ncclCommUserRank failed");
+    const unsigned char *mine = static_cast<const unsigned char *>(atlas_dev) + (size_t)rank * band_bytes;
+    const int rc = all_gather(mine, atlas_dev, band_bytes, 0 /* ncclInt8 / ncclChar */, nccl_comm, ctx->stream);
+    if (rc != 0) return fail(FR_E_HIP, "fr_allgather_bands: ncclAllGather returned %d", rc);
     return FR_OK;
 }
 

@@ -145,6 +145,13 @@ inline Image::GlyphDebug glyphDebugRender(Context &ctx, const Glyph &glyph, uint
 }
 
 // a batch of glyphs -> one atlas (build-defined cell grid, fr_atlas_layout) of n x n-sample coverage
+// optional multi-GPU assembly (include/fr_raster.h): rank r rendered its band at atlas_dev + r * band_bytes; comm is the
+// host's ncclComm_t
+inline void allgatherBands(Context &ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes)
+{
+    check(fr_allgather_bands(ctx.get(), nccl_comm, atlas_dev, band_bytes));
+}
+
 inline Image::Gray renderAtlas(Context &ctx, const std::vector<Glyph> &glyphs, FontInformation font_info, uint16_t font_size,
                                uint32_t cell, uint32_t cols, int samples_per_axis)
 {

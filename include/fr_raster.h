@@ -221,6 +221,15 @@ int fr_atlas_layout(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyp
                     uint32_t cell, uint32_t cols, uint32_t rows_per_page,
                     fr_job *jobs_out, uint32_t *page_of_job, uint32_t *n_pages);
 
+/* ---- multi-GPU assembly (optional; SURVEY section 8e: "optional final assembly: all-gather of row bands") --------
+ * The hot path needs no collective: every rank renders its own glyph range into its own band.  When one rank (or all)
+ * wants the whole atlas, the bands are equal-sized slices of one buffer — rank r rendered into
+ * atlas_dev + r * band_bytes — and this call runs RCCL's in-place ncclAllGather over them on the context's stream.
+ * nccl_comm is an ncclComm_t the HOST created (ncclCommInitRank / torch.distributed own the rendezvous; the library
+ * never does); the call binds to the RCCL that is already loaded in the process (dlsym, no link-time dependency) and
+ * returns FR_E_UNSUPPORTED if there is none.  Asynchronous like fr_plan_render: fr_ctx_sync / stream order apply.   */
+int fr_allgather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes);
+
 /* ---- contour producer (host side): TrueType glyf/loca -> Glyph contour layout ------------
  * What font/Font.zig + font/ttf.zig + font/Glyph.zig do in the reference (Font.initTTF :31,
  * loadGlyph :171, SimpleGlyph.initFromReader ttf.zig:759, ComponentGlyph ttf.zig:830,

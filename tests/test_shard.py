@@ -97,3 +97,47 @@ def test_two_ranks_render_with_the_library_on_one_gpu(oracle):
     """the N > 1 path with the product in it: two gloo ranks, each with its own fr_ctx on the box's one GPU,
     render their shards through libfr_raster and gather; equal to the oracle's unsharded bytes"""
     _check_two_rank_gather(oracle, 22, True)
+
+
+@pytest.mark.gpu
+def test_allgather_bands_through_the_c_abi_with_a_one_rank_communicator():
+    """fr_allgather_bands (include/fr_raster.h): the optional RCCL assembly of row bands at the C boundary.  One GPU
+    is all this box has, so the communicator has ONE rank — RCCL's own C API creates it (ncclGetUniqueId /
+    ncclCommInitRank through ctypes, as a C or Zig host would), the library finds that RCCL in the process, runs the
+    in-place all-gather on the context's stream and leaves the rendered band as it was."""
+    import ctypes as C
+    import font_renderer_amd as fr
+    from font_renderer_amd import _lib as L
+    from font_renderer_amd.atlas import atlas_shape, cell_jobs
+    from font_renderer_amd.synth import synth_glyphset
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        stream = torch.cuda.Stream()
+        ctx = fr.Context(0, stream.cuda_stream)
+        gs = synth_glyphset(8, 32, first_index=4242)
+        jobs = cell_jobs(gs, 128, 128, 2048, 4)
+        H, W = atlas_shape(8, 128, 4)
+        with torch.cuda.stream(stream):
+            band = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+        plan = fr.Plan(fr.DeviceGlyphSet(ctx, gs), jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+        plan.render(band.data_ptr(), W, H)
+        ctx.sync()
+        before = band.cpu().numpy().copy()
+        lib = L.load_library()
+        L.check(lib.fr_allgather_bands(ctx._h, comm, C.c_void_p(band.data_ptr()), band.numel()))
+        ctx.sync()
+        assert np.array_equal(band.cpu().numpy(), before) and before.max() == 255
+        # a context without a communicator is refused, not dereferenced
+        assert lib.fr_allgather_bands(ctx._h, None, C.c_void_p(band.data_ptr()), band.numel()) != 0
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
