@@ -25,6 +25,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 import numpy as np  # noqa: E402
 
+RAMP_S = 0.25                  # untimed renders before --warmup (reported as "ramp_s" / "ramp_steps")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DEJAVU = "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"
 
@@ -53,14 +54,34 @@ WORKLOADS = {
     "c3_cjk21k_256px_s128_winding_i16": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="winding_i16"),
     # the reference's own product on the real font: renderGlyph's gray map of every DejaVuSerif-Italic glyph, 6 sizes
     "real_dejavuserif_italic_whole_font_256px_gray_debug": dict(glyphs=0, cell=256, segs=0, n=1, cols=64, gen="font", font=DEJAVU, mode="gray_debug"),
+    # the reference's literal product in batch (render_glyph.zig:11-33): every glyph of the font at EXACTLY renderGlyph's own
+    # image size for font_size 64 (47 x 45-ish images), shelf-packed tight into one atlas — ragged cells on the fast kernels
+    "real_dejavuserif_italic_renderglyph_dims_size64_gray_debug": dict(glyphs=0, cell=0, segs=0, n=1, cols=0, gen="font_dims", font=DEJAVU, mode="gray_debug", sizes=(64,), atlas_w=4096),
+    "real_dejavuserif_italic_renderglyph_dims_size64_16spp": dict(glyphs=0, cell=0, segs=0, n=4, cols=0, gen="font_dims", font=DEJAVU, sizes=(64,), atlas_w=4096),
+    # the same product over the sizes a text renderer asks for (12 ... 256): 12 images per glyph
+    "real_dejavuserif_italic_renderglyph_dims_sizes12to256_gray_debug": dict(glyphs=0, cell=0, segs=0, n=1, cols=0, gen="font_dims", font=DEJAVU, mode="gray_debug", sizes=(12, 16, 20, 24, 32, 48, 64, 96, 128, 160, 200, 256), atlas_w=8192),
+    "real_dejavuserif_italic_renderglyph_dims_sizes12to256_16spp": dict(glyphs=0, cell=0, segs=0, n=4, cols=0, gen="font_dims", font=DEJAVU, sizes=(12, 16, 20, 24, 32, 48, 64, 96, 128, 160, 200, 256), atlas_w=8192),
 }
 
 
 def build_inputs(wl, rank, lo, hi):
     """-> (GlyphSet, jobs, (H, W)) for this rank's glyph range [lo, hi) of the workload"""
-    from font_renderer_amd.atlas import atlas_shape, cell_jobs
+    from font_renderer_amd.atlas import atlas_shape, cell_jobs, glyph_dims_jobs
     from font_renderer_amd.synth import stroke_glyphset, synth_glyphset
     cell, cols, gen = wl["cell"], wl["cols"], wl.get("gen", "synth")
+    if gen == "font_dims":
+        import font_renderer_amd as fr
+        font = fr.Font.initTTF(wl["font"])
+        gs, kept = font.glyphset()
+        upm = font.information.units_per_em
+        W = wl["atlas_w"]
+        parts, y = [], 0
+        for size in wl["sizes"]:                                   # one run of shelves per font size
+            jb, h = glyph_dims_jobs(gs, size, upm, W)
+            jb["out_y"] += y
+            y += h
+            parts.append(jb)
+        return gs, np.concatenate(parts), (y, W)
     if gen == "font":
         import font_renderer_amd as fr
         font = fr.Font.initTTF(wl["font"])
@@ -189,9 +210,11 @@ def main():
     # the GPU's clocks come up over the first ~0.1 s of load (a timed region right after an idle start runs up to 11 %
     # slower than the kernel: DESIGN.md section 7): 0.25 s of untimed renders first, whatever --warmup says
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.25:
+    ramp_steps = 0
+    while time.perf_counter() - t_ramp < RAMP_S:
         for _ in range(8):
             step()
+        ramp_steps += 8
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -249,6 +272,7 @@ def main():
     # Beside it the launch PERIOD of the timed region (the events above / steps): the same number once the clocks are up
     # (they take ~100 launches: with --warmup 5 a 0.29 ms kernel ran at a period of 0.32 ms).
     kms = sorted(plan.render_timed(out.data_ptr(), W, H) for _ in range(max(5, min(args.steps, 20))))
+    launches = plan.describe()                                 # the instances this plan launches, as rocprofv3 names them
     k_ms = float(np.mean(kms))
     achieved = pixels * bpp / (k_ms * 1e-3) / 1e9             # GB/s of algorithmic bytes (1 B / pixel; 2 for int16 windings)
     traffic, traffic_src = None, None
@@ -260,22 +284,14 @@ def main():
                 traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:
             traffic = None
-    if mode == fr.FR_SDF_U8:
-        sign = "fr::win1_kernel<mask>" if pstats["jobs_general"] == 0 else ("fr::render_kernel<COVERAGE_U8,1>" if pstats["jobs_cov4"] == 0 else "fr::win1_kernel<mask> + fr::render_kernel<COVERAGE_U8,1>")
-        kname = f"{sign} (sign pass) + fr::sdf_kernel"
-    elif pstats["jobs_general"] == 0 and mode == fr.FR_COVERAGE_U8 and n == 4:
-        kname = f"fr::cov4_kernel<{4 if wl['cell'] % 256 == 0 else 3},32>"
-    elif pstats["jobs_general"] == 0:
-        kname = f"fr::win1_kernel<{4 if wl['cell'] % 256 == 0 else 3},{mode_name}>"
-    elif pstats["jobs_cov4"] == 0:
-        kname = f"fr::render_kernel<{mode_name},{n}>"
-    else:
-        kname = f"fr::{'cov4' if n == 4 else 'win1'}_kernel ({pstats['jobs_cov4']} jobs) + fr::render_kernel ({pstats['jobs_general']} jobs)"
+    # the dominant kernel = the launch with the most jobs (SDF: the distance kernel, which follows the sign pass)
+    parts = [q.rsplit(" x", 1) for q in launches.split("; ")]
+    kname = ("fr::sdf_kernel" + parts[-1][0].split("fr::sdf_kernel")[1]) if mode == fr.FR_SDF_U8 else max(parts, key=lambda q: int(q[1]))[0]
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "launches": launches, "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": pixels * bpp, "kernel_ms": round(k_ms, 4), "period_ms": round(float(gpu_ms), 4),
                 "frac_of_period": round(pixels * bpp / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "timing": "kernel_ms: HIP events around each launch (== rocprofv3 kernel duration); period_ms: HIP events around the timed region's back-to-back launches / steps",
+                "timing": "kernel_ms: HIP events around each fr_plan_render (all of `launches`; == the rocprofv3 kernel duration when there is one launch); period_ms: HIP events around the timed region's back-to-back renders / steps",
                 "build_id": fr.build_id()}
 
     # ---- configs[0]: the reference's own call shape — one glyph, one image (STIX 'A' at 64 -> 47 x 45), latency per call
@@ -317,25 +333,31 @@ def main():
                  "winding_i16": oracle_lib.WINDING_I16}[mode_name]
         odt = np.int16 if bpp == 2 else np.uint8
         center = phase == fr.FR_SAMPLE_CENTER
+        Wd = int(W)
+
+        def sample(k, th):
+            """the oracle on the first k jobs (their own rectangles of an atlas as wide as the GPU's) -> (seconds, buffer)"""
+            rows = int((jobs["out_y"][:k].astype(np.int64) + jobs["h"][:k]).max())
+            buf = np.zeros((rows, Wd), odt)
+            t = time.perf_counter()
+            orc.render_batch(gs, jobs[:k], omode, buf, n, center, th)
+            return time.perf_counter() - t, buf
+
         probe = min(2, G)
-        buf = np.zeros(atlas_shape(probe, cell, cols), odt)
-        t = time.perf_counter()
-        orc.render_batch(gs, jobs[:probe], omode, buf, n, center, 1)
-        per_glyph = (time.perf_counter() - t) / probe
-        ng = int(max(threads, min(G, args.cpu_seconds * threads / max(per_glyph, 1e-9))))
-        unit = max(threads, cols)                      # whole atlas rows, so the sample can be compared with the GPU's bytes
-        ng = min(G, (ng // unit) * unit if ng >= unit else ng)
-        buf = np.zeros(atlas_shape(ng, cell, cols), odt)
-        t = time.perf_counter()
-        orc.render_batch(gs, jobs[:ng], omode, buf, n, center, threads)
-        ct = time.perf_counter() - t
+        per_job = sample(probe, 1)[0] / probe
+        px = jobs["w"].astype(np.int64) * jobs["h"]
+        ng = int(max(min(threads, G), min(G, args.cpu_seconds * threads / max(per_job, 1e-9))))
+        ct, buf = sample(ng, threads)
         with torch.cuda.stream(stream):
-            same = bool(np.array_equal(out[:buf.shape[0]].cpu().numpy(), buf)) if (ng % cols == 0 or ng <= cols) else None
-        cpu = {"value": round(ng * cell * cell / ct / 1e6, 4), "unit": "Mpixel/s", "cores": threads, "kind": "port",
-               "sample": f"first {ng} cells of the same workload ({cell}x{cell}, {n * n} samples/pixel), "
+            gpu = out[:buf.shape[0]].cpu().numpy()
+        same = all(np.array_equal(gpu[j["out_y"]:j["out_y"] + j["h"], j["out_x"]:j["out_x"] + j["w"]],
+                                  buf[j["out_y"]:j["out_y"] + j["h"], j["out_x"]:j["out_x"] + j["w"]]) for j in jobs[:ng])
+        shape = f"{cell}x{cell}" if cell else "renderGlyph-sized"
+        cpu = {"value": round(float(px[:ng].sum()) / ct / 1e6, 4), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+               "sample": f"first {ng} cells of the same workload ({shape}, {n * n} samples/pixel, {int(px[:ng].sum())} pixels), "
                          f"{ct:.1f} s wall on {threads} threads, oracle/fr_oracle.c (C restatement of "
                          f"render_glyph.zig, not the Zig binary)",
-               "single_thread_value": round(cell * cell / per_glyph / 1e6, 4), "matches_gpu_bytes": same}
+               "single_thread_value": round(float(px[:probe].sum()) / probe / per_job / 1e6, 4), "matches_gpu_bytes": bool(same)}
 
     if rank == 0:
         line = {
@@ -343,7 +365,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if wl.get("gen", "synth") in ("synth", "stroke") else "real font outlines (matplotlib's DejaVuSerif-Italic / the committed ASCII fixture), random-free",
-            "config": {"workload": args.workload, "cells_per_gpu": G, "glyphs_in_set": len(gs), "cell": f"{cell}x{cell}",
+            "ramp_s": RAMP_S, "ramp_steps": ramp_steps,
+            "config": {"workload": args.workload, "cells_per_gpu": G, "glyphs_in_set": len(gs),
+                       "cell": f"{cell}x{cell}" if cell else f"renderGlyph's own image per glyph (render_glyph.zig:14-19), font sizes {list(wl['sizes'])}",
                        "segments_per_glyph": S if S else "as in the font", "total_segments_in_set": stats["segments"],
                        "samples_per_pixel": n * n, "mode": mode_name if mode_name != "coverage" else "coverage_u8",
                        "pixels_per_step_per_gpu": pixels, "pixels_per_step_whole_job": tot_pixels,

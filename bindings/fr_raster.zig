@@ -66,6 +66,7 @@ pub extern "c" fn fr_plan_render(plan: *fr_plan, out_dev: *anyopaque, out_stride
 pub extern "c" fn fr_plan_render_timed(plan: *fr_plan, out_dev: *anyopaque, out_stride: usize, out_rows: usize, ms: *f32) c_int;
 pub extern "c" fn fr_plan_pixels(plan: *const fr_plan) u64;
 pub extern "c" fn fr_plan_stats(plan: *const fr_plan, n_jobs_cov4: ?*u32, n_jobs_general: ?*u32) c_int;
+pub extern "c" fn fr_plan_describe(plan: *const fr_plan, buf: [*]u8, cap: usize) c_int;
 pub extern "c" fn fr_allgather_bands(ctx: *fr_ctx, nccl_comm: *anyopaque, atlas_dev: *anyopaque, band_bytes: usize) c_int;
 pub extern "c" fn fr_render_batch(ctx: *fr_ctx, gs: *const fr_glyphset, jobs: [*]const Job, n_jobs: u32, params: *const RasterParams, out_host: *anyopaque, out_stride: usize, out_rows: usize) c_int;
 // ---- renderGlyph drop-in
@@ -81,6 +82,7 @@ pub extern "c" fn fr_exact_lattice(ctx: *fr_ctx, points_xy: [*]const i16, contou
 pub extern "c" fn fr_exact_coverage(ctx: *fr_ctx, points_xy: [*]const i16, contour_start: [*]const u32, n_contours: u32, k: u32, x0: i32, y0: i32, w_px: u32, h_px: u32, n: u32, out_host: [*]u8) c_int;
 // ---- atlas layout (host side)
 pub extern "c" fn fr_atlas_layout(boxes: [*]const i16, n_glyphs: u32, first_glyph: u32, units_per_em: [*]const u16, n_upm: u32, font_size: u16, cell: u32, cols: u32, rows_per_page: u32, jobs_out: [*]Job, page_of_job: ?[*]u32, n_pages: ?*u32) c_int;
+pub extern "c" fn fr_atlas_layout_glyph_dims(boxes: [*]const i16, n_glyphs: u32, first_glyph: u32, units_per_em: [*]const u16, n_upm: u32, font_size: u16, atlas_w: u32, @"align": u32, jobs_out: [*]Job, atlas_h: ?*u32) c_int;
 // ---- contour producer (host side; the Zig host has font/Font.zig and does not need it)
 pub extern "c" fn fr_font_open(ttf_bytes: *const anyopaque, len: usize, flags: u32, out: *?*fr_font) c_int;
 pub extern "c" fn fr_font_close(font: ?*fr_font) void;
@@ -105,6 +107,13 @@ fn context() Error!*fr_ctx {
         if (fr_ctx_create(0, null, &g_ctx) != 0) return error.RasterFailed;
     }
     return g_ctx.?;
+}
+
+/// Releases the process-wide context (its stream, device arena and pinned staging block).  Call once from the
+/// host's shutdown path, next to Font.deinit (src/main.zig:33); a later renderGlyph creates a fresh one.
+pub fn deinit() void {
+    if (g_ctx) |c| fr_ctx_destroy(c);
+    g_ctx = null;
 }
 
 /// Flat view of a Glyph: every contour's points live in ONE allocation in contour order

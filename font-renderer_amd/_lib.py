@@ -55,6 +55,7 @@ SYMBOLS = [
     ("fr_plan_render_timed", C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     ("fr_plan_pixels", C.c_uint64, [_P]),
     ("fr_plan_stats", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("fr_plan_describe", C.c_int, [_P, C.c_char_p, C.c_size_t]),
     ("fr_allgather_bands", C.c_int, [_P, _P, _P, C.c_size_t]),
     ("fr_render_batch", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(RasterParams), _P, C.c_size_t, C.c_size_t]),
     ("fr_render_glyph_dims", C.c_int, [_P, C.c_uint16, C.c_uint16, _P, _P, C.POINTER(C.c_uint16),
@@ -66,6 +67,8 @@ SYMBOLS = [
     ("fr_glyph_debug_render", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint8, _P]),
     ("fr_atlas_layout", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, C.c_uint32,
                                   _P, _P, C.POINTER(C.c_uint32)]),
+    ("fr_atlas_layout_glyph_dims", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, _P,
+                                             C.POINTER(C.c_uint32)]),
     ("fr_exact_lattice", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, _P]),
     ("fr_exact_coverage", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("fr_font_open", C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(_P)]),

@@ -37,6 +37,21 @@ def cell_jobs(gs: GlyphSet, cell: int, font_size: int, units_per_em, cols: int, 
     return jobs
 
 
+def glyph_dims_jobs(gs: GlyphSet, font_size: int, units_per_em, atlas_w: int, *, align: int = 1, first_glyph: int = 0,
+                    n_glyphs: int | None = None):
+    """fr_job table of the reference's own product in batch: glyph i at exactly renderGlyph's image size
+    (render_glyph.zig:13-19), shelf-packed into an atlas_w-wide atlas (fr_atlas_layout_glyph_dims) -> (jobs, atlas_h)"""
+    n = len(gs) - first_glyph if n_glyphs is None else n_glyphs
+    jobs = np.zeros(n, JOB_DTYPE)
+    upm = np.broadcast_to(np.asarray(units_per_em), (len(gs),))[first_glyph:first_glyph + n]
+    upm = np.ascontiguousarray(upm, np.uint16) if n else np.ones(1, np.uint16)
+    boxes = np.ascontiguousarray(gs.boxes[first_glyph:first_glyph + n], np.int16)
+    h = C.c_uint32()
+    L.check(L.load_library().fr_atlas_layout_glyph_dims(L.ptr(boxes), n, first_glyph, L.ptr(upm), len(upm) if n else 1, font_size,
+                                                        atlas_w, align, L.ptr(jobs), C.byref(h)))
+    return jobs, h.value
+
+
 def atlas_shape(n_glyphs: int, cell: int, cols: int):
     rows = (n_glyphs + cols - 1) // cols
     return rows * cell, cols * cell

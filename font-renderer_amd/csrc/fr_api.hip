@@ -19,10 +19,10 @@
 namespace fr {
 void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, Rec *,
                     uint32_t *, hipStream_t);
-hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t);
+hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
 uint32_t render_wg_waves();
-hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, hipStream_t);
-hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t);
+hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, int ns, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
+hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
 hipError_t launch_sdf(const RenderArgs &, uint32_t, uint32_t, uint32_t max_seg, int cull, hipStream_t);
@@ -110,11 +110,14 @@ struct fr_plan {
     uint32_t *d_large = nullptr;       // distinct glyphs of more than 128 segments among the jobs: their records are
     uint32_t n_large = 0;              // rebuilt by prepare_kernel before every render (the others: inside the render kernel)
     uint32_t n_jobs = 0;
-    // jobs cov4_kernel takes (fr_cov4.hip: 16-sample coverage, uniform cells, <= 256 root records): the first n_fast
-    // entries of d_jobs / d_job_seg; the general kernel renders the other n_jobs - n_fast
-    uint32_t n_fast = 0;               // (of which the first n_fast128 need <= 128 record slots, up to n_fast256 <= 256, the rest <= 512)
-    uint32_t n_fast128 = 0, n_fast256 = 0;
-    uint32_t fast_bands = 0, fast_strips = 0, gen_bands = 0, gen_strips = 0;
+    // jobs cov4_kernel / win1_kernel take (fr_cov4.hip, fr_win1.hip): the first n_fast entries of d_jobs / d_job_seg, grouped
+    // into `parts` — one launch each, by strip width (64 / 128 / 256 pixels, from the job's own width) and by the record
+    // slots the glyph needs (128 / 256 / 512); the general kernel renders the other n_jobs - n_fast
+    uint32_t n_fast = 0;
+    struct Part { uint32_t first, cnt, wlog, rec_cap, bands, strips; uint64_t pixels; };
+    std::vector<Part> parts;
+    int fast_ns = 0;                   // samples per axis of the fast kernels' jobs (4 / 2: cov4_kernel, 1: win1_kernel)
+    uint32_t gen_bands = 0, gen_strips = 0;
     bool gen_uniform = false;
     fr_raster_params params{};
     uint32_t bands = 0, strips = 0, strip_w = 0, max_w = 0, max_h = 0;
@@ -129,7 +132,10 @@ extern "C" {
 
 int fr_abi_version(void) { return FR_ABI_VERSION; }
 const char *fr_last_error(void) { return g_err; }
-const char *fr_build_id(void) { return "r02.14"; }
+#ifndef FR_BUILD_ID
+#error "FR_BUILD_ID comes from the Makefile (a hash of the sources)"
+#endif
+const char *fr_build_id(void) { return FR_BUILD_ID; }
 
 int fr_ctx_create(int device, void *hip_stream, fr_ctx **out)
 {
@@ -232,6 +238,108 @@ static int flatten_segments(const uint32_t *contour_start, uint32_t n_contours, 
     return FR_OK;
 }
 
+}  // extern "C"
+
+// Upper bound of the root records a render can keep for a glyph (segments [s0, s1)): the two candidates of a segment
+// minus those build_record_rows (fr_records.hpp) discards without looking at a cell — a == 0: one root, none if
+// p2y == p0y (render_glyph.zig:49-50); else the far-side root when t_v = B/a >= 1 and the near-side root when t_v < 0.
+static uint32_t glyph_root_bound(const int16_t *points_xy, const uint32_t *seg_p0, uint32_t s0, uint32_t s1)
+{
+    uint32_t nb = 0;
+    for (uint32_t sgi = s0; sgi < s1; ++sgi) {
+        const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
+        const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
+        const int32_t a = p0y - 2 * p1y + p2y, b = p0y - p1y;
+        if (a == 0) { nb += (p2y != p0y) ? 1u : 0u; continue; }
+        const int64_t ba = (int64_t)b * a;
+        const bool tv_lt0 = ba < 0, tv_ge1 = a > 0 ? b >= a : b <= a;
+        nb += (tv_ge1 ? 0u : 1u) + (tv_lt0 ? 0u : 1u);
+    }
+    return nb;
+}
+
+// Estimate of the most crossings one horizontal ray can have with a glyph: a sweep over the segments' y extents (the
+// control points bound the curve), counted once between the heights of its ends and twice where it overshoots them.
+// Glyphs that stay at or under 16 take the instance that keeps 16 crossings per sample row in registers (plan_classify).
+// `ev` is scratch: (2 y + [closing], +-weight) — openings sort before closings at one y.
+static uint32_t glyph_ray_bound(const int16_t *points_xy, const uint32_t *seg_p0, uint32_t s0, uint32_t s1,
+                                std::vector<std::pair<int32_t, int32_t>> &ev)
+{
+    ev.clear();
+    for (uint32_t sgi = s0; sgi < s1; ++sgi) {
+        const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
+        const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
+        // between the heights of its two ends a quadratic is met once; where it overshoots them (towards the
+        // control point: the vertex lies inside) twice, and not at all between the ends' heights on that side
+        const int32_t clo = std::min(p0y, p2y), chi = std::max(p0y, p2y);
+        // (half-open at the ends' heights, as the reference's own t in [0, 1) is: two segments that meet at a
+        // vertex are not both counted there.  An estimate that steers jobs, not a proof: a row that does hold
+        // more than the instance keeps takes the exact direct sum)
+        ev.emplace_back(2 * clo, 1);
+        ev.emplace_back(2 * chi, -1);
+        // (the vertex overshoots the nearer end by at most half of what the control point does)
+        if (p1y > chi) { ev.emplace_back(2 * chi, 2); ev.emplace_back(2 * (chi + (p1y - chi + 1) / 2) + 1, -2); }
+        if (p1y < clo) { ev.emplace_back(2 * (clo - (clo - p1y + 1) / 2), 2); ev.emplace_back(2 * clo, -2); }
+    }
+    std::sort(ev.begin(), ev.end());
+    int32_t cur = 0, best = 0;
+    for (const auto &e : ev) { cur += e.second; best = std::max(best, cur); }
+    return (uint32_t)best;
+}
+
+// Which kernel renders a job.  cov4_kernel (ns x ns samples, ns in {2, 4}) and win1_kernel (one sample per pixel)
+// take cells of ANY width and height — renderGlyph's own image size (render_glyph.zig:14-19) included — up to 2048
+// sample rows, of glyphs with <= 384 segments and <= 512 root records the vertex rule cannot discard: in strips of
+// 64 / 128 / 256 pixels chosen from the job's own width (a 47 x 45 image does not pay for 256 columns) and bands of
+// 64 sample rows, the last strip and band clipped at the cell's border.  Everything else takes the general
+// render_kernel.  -> 0 (general) or 1 + 3 (wlog - 2) + record class (0: <= 128 slots and <= 16 crossings per ray
+// estimated, 1: <= 256 slots, 2: <= 512).
+struct FastRule {
+    int ns = 0;             // samples per axis on the fast kernels (0: this plan has no fast kernel)
+    uint32_t wlog_max = 0;  // widest strip the context allows (option "strip_px")
+};
+static FastRule fast_rule(const fr_ctx *ctx, const fr_raster_params *params)
+{
+    FastRule r;
+    const int n = params->samples_per_axis;
+    const bool one = params->mode == FR_WINDING_I16 || params->mode == FR_GRAY_DEBUG || params->mode == FR_MASK_NONZERO ||
+                     (params->mode == FR_COVERAGE_U8 && n == 1) || params->mode == FR_SDF_U8;   // (SDF: its sign pass)
+    r.wlog_max = ctx->strip_px >= 256u ? 4u : (ctx->strip_px >= 128u ? 3u : (ctx->strip_px >= 64u ? 2u : 0u));
+    if (ctx->cov4 && r.wlog_max) r.ns = one ? 1 : ((params->mode == FR_COVERAGE_U8 && (n == 4 || n == 2)) ? n : 0);
+    return r;
+}
+static int fast_class(const FastRule &R, uint32_t w, uint32_t h, uint32_t nsg, uint32_t root_bound, uint32_t ray_bound)
+{
+    if (!R.ns || w == 0 || h == 0 || (uint64_t)h * (uint32_t)R.ns > 2048u) return 0;     // (12-bit sample-row fields)
+    if (nsg > fr::cov4_max_segments() || root_bound > 512u) return 0;
+    const uint32_t wl = std::min(w <= 64u ? 2u : (w <= 128u ? 3u : 4u), R.wlog_max);
+    const int rc = (nsg <= 256u && root_bound <= 128u && ray_bound <= 16u) ? 0 : ((nsg <= 256u && root_bound <= 256u) ? 1 : 2);
+    return 1 + 3 * (int)(wl - 2u) + rc;
+}
+// the fast jobs of `order` (already grouped by class, `counts[c]` jobs of class c + 1) -> the plan's launches
+static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[9], int ns)
+{
+    p->parts.clear();
+    p->fast_ns = ns;
+    const uint32_t prb = ns == 1 ? 16u : 64u / (uint32_t)ns;          // pixel rows of a band
+    uint32_t first = 0;
+    for (int c = 0; c < 9; ++c) {
+        if (!counts[c]) continue;
+        fr_plan::Part pt{};
+        pt.first = first; pt.cnt = counts[c]; pt.wlog = 2u + (uint32_t)(c / 3); pt.rec_cap = 128u << (c % 3);
+        const uint32_t sw = 16u << pt.wlog;
+        for (uint32_t q = first; q < first + counts[c]; ++q) {
+            pt.bands = std::max(pt.bands, (sorted_jobs[q].h + prb - 1u) / prb);
+            pt.strips = std::max(pt.strips, (sorted_jobs[q].w + sw - 1u) / sw);
+            pt.pixels += (uint64_t)sorted_jobs[q].w * sorted_jobs[q].h;
+        }
+        p->parts.push_back(pt);
+        first += counts[c];
+    }
+}
+
+extern "C" {
+
 void fr_glyphset_destroy(fr_glyphset *gs)
 {
     if (!gs) return;
@@ -275,51 +383,12 @@ int fr_glyphset_create(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *co
     }
     uint32_t max_seg = 0;
     for (uint32_t g = 0; g < n_glyphs; ++g) max_seg = std::max(max_seg, gseg[g + 1] - gseg[g]);
-    // Upper bound of the root records a render can keep per glyph: the two candidates of a segment minus those
-    // build_record_rows (fr_records.hpp) discards without looking at a cell — a == 0: one root, none if p2y == p0y
-    // (render_glyph.zig:49-50); else the far-side root when t_v = B/a >= 1 and the near-side root when t_v < 0.
-    std::vector<uint32_t> root_bound(n_glyphs, 0u);
-    for (uint32_t g = 0; g < n_glyphs; ++g) {
-        uint32_t nb = 0;
-        for (uint32_t sgi = gseg[g]; sgi < gseg[g + 1]; ++sgi) {
-            const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
-            const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
-            const int32_t a = p0y - 2 * p1y + p2y, b = p0y - p1y;
-            if (a == 0) { nb += (p2y != p0y) ? 1u : 0u; continue; }
-            const int64_t ba = (int64_t)b * a;
-            const bool tv_lt0 = ba < 0, tv_ge1 = a > 0 ? b >= a : b <= a;
-            nb += (tv_ge1 ? 0u : 1u) + (tv_lt0 ? 0u : 1u);
-        }
-        root_bound[g] = nb;
-    }
-    // Estimate of the most crossings one horizontal ray can have with a glyph: a sweep over the segments' y extents
-    // (the control points bound the curve), counted once between the heights of its ends and twice where it overshoots
-    // them.  Glyphs
-    // that stay at or under 16 take the instance that keeps 16 crossings per sample row in registers (fr_plan_create).
-    std::vector<uint32_t> ray_bound(n_glyphs, 0u);
+    std::vector<uint32_t> root_bound(n_glyphs, 0u), ray_bound(n_glyphs, 0u);
     {
-        std::vector<std::pair<int32_t, int32_t>> ev;     // (2 y + [closing], +-weight): openings sort before closings at one y
+        std::vector<std::pair<int32_t, int32_t>> ev;
         for (uint32_t g = 0; g < n_glyphs; ++g) {
-            ev.clear();
-            for (uint32_t sgi = gseg[g]; sgi < gseg[g + 1]; ++sgi) {
-                const int16_t *q = points_xy + 2u * (size_t)seg_p0[sgi];
-                const int32_t p0y = q[1], p1y = q[3], p2y = q[5];
-                // between the heights of its two ends a quadratic is met once; where it overshoots them (towards the
-                // control point: the vertex lies inside) twice, and not at all between the ends' heights on that side
-                const int32_t clo = std::min(p0y, p2y), chi = std::max(p0y, p2y);
-                // (half-open at the ends' heights, as the reference's own t in [0, 1) is: two segments that meet at a
-                // vertex are not both counted there.  An estimate that steers jobs, not a proof: a row that does hold
-                // more than the instance keeps takes the exact direct sum)
-                ev.emplace_back(2 * clo, 1);
-                ev.emplace_back(2 * chi, -1);
-                // (the vertex overshoots the nearer end by at most half of what the control point does)
-                if (p1y > chi) { ev.emplace_back(2 * chi, 2); ev.emplace_back(2 * (chi + (p1y - chi + 1) / 2) + 1, -2); }
-                if (p1y < clo) { ev.emplace_back(2 * (clo - (clo - p1y + 1) / 2), 2); ev.emplace_back(2 * clo, -2); }
-            }
-            std::sort(ev.begin(), ev.end());
-            int32_t cur = 0, best = 0;
-            for (const auto &e : ev) { cur += e.second; best = std::max(best, cur); }
-            ray_bound[g] = (uint32_t)best;
+            root_bound[g] = glyph_root_bound(points_xy, seg_p0.data(), gseg[g], gseg[g + 1]);
+            ray_bound[g] = glyph_ray_bound(points_xy, seg_p0.data(), gseg[g], gseg[g + 1], ev);
         }
     }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -448,65 +517,55 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     p->max_w = max_w; p->max_h = max_h;
     const uint32_t band = 64u / n;                                      // pixel rows per wave band
     const uint32_t cap_w = ctx->strip_px;                               // strip width cap, pixels
-    uint32_t sw = (max_w + 15u) & ~15u;
-    if (sw > cap_w) sw = cap_w;
-    if (sw == 0) sw = 16;
-    p->strip_w = sw;
-    p->bands = max_h ? (max_h + band - 1) / band : 1;
-    p->strips = max_w ? (max_w + sw - 1) / sw : 1;
-    // Per JOB: cov4_kernel (fr_cov4.hip) takes 16-sample coverage of cells that are whole 128- / 256-pixel strips
-    // wide, whole wave bands (16 pixel rows) and at most 256 pixels tall, of glyphs with at most 256 segments and
-    // 256 possible root records; the general kernel takes the rest.  The job table is stored fast jobs first.
+    // Per JOB: the fast kernels or the general one (fast_class above).  The job table is stored fast jobs first, grouped
+    // by class — one launch per class that occurs.
     std::vector<uint32_t> order(n_jobs);
     uint32_t n_fast = 0;
+    uint32_t counts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const FastRule rule = fast_rule(ctx, params);
     {
-        // (cov4_kernel: 16 samples per pixel; win1_kernel: the one-sample modes, cells up to 1024 pixels tall)
-        const bool one = params->mode == FR_WINDING_I16 || params->mode == FR_GRAY_DEBUG || params->mode == FR_MASK_NONZERO ||
-                         (params->mode == FR_COVERAGE_U8 && n == 1u) || params->mode == FR_SDF_U8;   // (SDF: its sign pass)
-        const bool mode_ok = ctx->cov4 && (sw == 128u || sw == 256u) && ((params->mode == FR_COVERAGE_U8 && n == 4u) || one);
-        const uint32_t max_h_fast = one ? 2048u : 512u;                  // (sample rows <= 2048: 12-bit row fields)
-        std::vector<uint32_t> mid256, mid, slow;
+        std::vector<uint8_t> cls(n_jobs);
         for (uint32_t j = 0; j < n_jobs; ++j) {
             const fr_job &jb = jobs[j];
             const uint32_t nsg = gs->h_glyph_seg_start[jb.glyph + 1] - gs->h_glyph_seg_start[jb.glyph];
-            const bool fast = mode_ok && jb.w != 0 && jb.h != 0 && jb.w % sw == 0 && jb.h % 16u == 0 && jb.h <= max_h_fast &&
-                              nsg <= fr::cov4_max_segments();
-            const uint32_t rb = gs->h_root_bound[jb.glyph];
-            // (the 128-record instance keeps 16 crossings per sample row: glyphs whose rays can meet more go one tier up)
-            if (fast && nsg <= 256u && rb <= 128u && gs->h_ray_bound[jb.glyph] <= 16u) order[n_fast++] = j;
-            else if (fast && nsg <= 256u && rb <= 256u) mid256.push_back(j);
-            else if (fast && rb <= 512u) mid.push_back(j);     // (<= 384 segments, <= 512 roots the vertex rule cannot discard)
-            else slow.push_back(j);
+            cls[j] = (uint8_t)fast_class(rule, jb.w, jb.h, nsg, gs->h_root_bound[jb.glyph], gs->h_ray_bound[jb.glyph]);
+            if (cls[j]) { ++counts[cls[j] - 1]; ++n_fast; }
         }
-        p->n_fast128 = n_fast;
-        std::copy(mid256.begin(), mid256.end(), order.begin() + n_fast);
-        n_fast += (uint32_t)mid256.size();
-        p->n_fast256 = n_fast;
-        std::copy(mid.begin(), mid.end(), order.begin() + n_fast);
-        n_fast += (uint32_t)mid.size();
-        std::copy(slow.begin(), slow.end(), order.begin() + n_fast);
+        uint32_t at[10], run = 0;
+        for (int c = 0; c < 9; ++c) { at[c + 1] = run; run += counts[c]; }
+        at[0] = run;                                                      // the general kernel's jobs go last
+        for (uint32_t j = 0; j < n_jobs; ++j) order[at[cls[j]]++] = j;
     }
     p->n_fast = n_fast;
     // the general list: uniform = every strip of every job is full (w a multiple of the strip width) and every wave
     // band is full (h a multiple of 64 / n pixel rows) — atlas cells; the render kernel has instances for it
     p->uniform = n_jobs > n_fast;
-    uint32_t gmax_w = 0, gmax_h = 0, fmax_w = 0, fmax_h = 0;
-    for (uint32_t q = 0; q < n_jobs; ++q) {
+    uint32_t gmax_w = 0, gmax_h = 0;
+    for (uint32_t q = n_fast; q < n_jobs; ++q) {
+        gmax_w = std::max(gmax_w, jobs[order[q]].w); gmax_h = std::max(gmax_h, jobs[order[q]].h);
+    }
+    uint32_t sw = (gmax_w + 15u) & ~15u;                                // the general kernel's strip width
+    if (sw > cap_w) sw = cap_w;
+    if (sw == 0) sw = 16;
+    p->strip_w = sw;
+    for (uint32_t q = n_fast; q < n_jobs; ++q) {
         const fr_job &jb = jobs[order[q]];
-        if (q < n_fast) { fmax_w = std::max(fmax_w, jb.w); fmax_h = std::max(fmax_h, jb.h); continue; }
-        gmax_w = std::max(gmax_w, jb.w); gmax_h = std::max(gmax_h, jb.h);
         if (jb.w == 0 || jb.h == 0 || jb.w % sw || jb.h % band) p->uniform = false;
     }
     p->gen_bands = gmax_h ? (gmax_h + band - 1) / band : 1;
     p->gen_strips = gmax_w ? (gmax_w + sw - 1) / sw : 1;
-    p->fast_bands = fmax_h / 16u;
-    p->fast_strips = fmax_w ? fmax_w / sw : 1;
-    if ((uint64_t)n_jobs * p->bands * p->strips > 0x7fffffffull) {
-        delete p;
-        return fail(FR_E_UNSUPPORTED, "batch needs more than 2^31 workgroups; split it");
-    }
+    p->bands = p->gen_bands; p->strips = p->gen_strips;
     std::vector<fr_job> sorted_jobs(n_jobs);
     for (uint32_t q = 0; q < n_jobs; ++q) sorted_jobs[q] = jobs[order[q]];
+    make_parts(p, sorted_jobs.data(), counts, rule.ns);
+    {
+        bool too_many = (uint64_t)(n_jobs - n_fast) * p->gen_bands * p->gen_strips > 0x7fffffffull;
+        for (const auto &pt : p->parts) too_many = too_many || (uint64_t)pt.cnt * pt.bands * pt.strips > 0x7fffffffull;
+        if (too_many) {
+            delete p;
+            return fail(FR_E_UNSUPPORTED, "batch needs more than 2^31 workgroups; split it");
+        }
+    }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_jobs, (size_t)n_jobs * sizeof(fr::Job));
     if (e == hipSuccess && n_jobs)
@@ -553,6 +612,38 @@ int fr_plan_stats(const fr_plan *plan, uint32_t *n_jobs_cov4, uint32_t *n_jobs_g
     return FR_OK;
 }
 
+// the kernel instances a render of the plan launches, as rocprofv3 names them, with their job counts
+int fr_plan_describe(const fr_plan *plan, char *buf, size_t cap)
+{
+    if (!plan || !buf || cap == 0) return fail(FR_E_INVALID, "fr_plan_describe: NULL argument");
+    buf[0] = 0;
+    size_t at = 0;
+    auto add = [&](const char *name, uint32_t cnt) {
+        const int k = snprintf(buf + at, cap - at, "%s%s x%u", at ? "; " : "", name, cnt);
+        if (k > 0) at = std::min(cap - 1, at + (size_t)k);
+    };
+    fr::RenderArgs a{};
+    a.kmax = plan->ctx->kmax;
+    char name[96];
+    const int pm = plan->params.mode;
+    for (const auto &pt : plan->parts) {
+        a.strip_w = 16u << pt.wlog;
+        name[0] = 0;
+        if (plan->fast_ns > 1) (void)fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, nullptr, false, name, sizeof name);
+        else (void)fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, nullptr, false, name, sizeof name);
+        add(name, pt.cnt);
+    }
+    if (plan->n_jobs > plan->n_fast) {
+        a.strip_w = plan->strip_w; a.uniform = plan->uniform ? 1u : 0u;
+        name[0] = 0;
+        if (pm == FR_SDF_U8) (void)fr::launch_render(a, FR_COVERAGE_U8, 1, nullptr, false, name, sizeof name);
+        else (void)fr::launch_render(a, pm, plan->params.samples_per_axis, nullptr, false, name, sizeof name);
+        add(name, plan->n_jobs - plan->n_fast);
+    }
+    if (pm == FR_SDF_U8 && plan->n_jobs) add(plan->gs->max_seg_per_glyph > 64u ? "fr::sdf_kernel<true>" : "fr::sdf_kernel<false>", plan->n_jobs);
+    return FR_OK;
+}
+
 static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
 {
     if (!plan) return fail(FR_E_INVALID, "plan is NULL");
@@ -596,10 +687,11 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     // output.
     fr_ctx *const ctx = plan->ctx;
     hipStream_t gst = ctx->stream;
-    const uint32_t part_cnt[3] = {plan->n_fast128, plan->n_fast256 - plan->n_fast128, n_fast - plan->n_fast256};
-    const int big = part_cnt[0] >= part_cnt[1] ? (part_cnt[0] >= part_cnt[2] ? 0 : 2) : (part_cnt[1] >= part_cnt[2] ? 1 : 2);
-    const int n_launches = (n_gen ? 1 : 0) + (part_cnt[0] ? 1 : 0) + (part_cnt[1] ? 1 : 0) + (part_cnt[2] ? 1 : 0);
-    // (the largest fast part stays on the context's stream; every other launch of the plan goes beside it)
+    // (the largest fast launch stays on the context's stream; every other launch of the plan goes beside it)
+    size_t big = 0;
+    for (size_t i = 1; i < plan->parts.size(); ++i)
+        if (plan->parts[i].pixels > plan->parts[big].pixels) big = i;
+    const size_t n_launches = (n_gen ? 1u : 0u) + plan->parts.size();
     const bool forked = ctx->overlap && n_fast && n_launches > 1;
     if (forked) {
         if (!ctx->aux) {
@@ -631,21 +723,18 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         if (sdf) HIP_TRY(fr::launch_render(a, FR_COVERAGE_U8, 1, gst));
         else HIP_TRY(fr::launch_render(a, plan->params.mode, plan->params.samples_per_axis, gst));
     }
-    for (int part = 0; part < 3; ++part) {
-        // cov4_kernel / win1_kernel: the jobs that fit 128 record slots (two records per lane), 256 (four; both four
-        // workgroups per CU), then those that need 512 (eight per lane, three workgroups per CU)
-        const uint32_t first = part == 0 ? 0u : (part == 1 ? plan->n_fast128 : plan->n_fast256);
-        const uint32_t cnt = (part == 0 ? plan->n_fast128 : (part == 1 ? plan->n_fast256 : n_fast)) - first;
-        const uint32_t rec_cap = part == 0 ? 128u : (part == 1 ? 256u : 512u);
-        if (!cnt) continue;
-        a.jobs = plan->d_jobs + first;
-        a.job_seg = plan->d_job_seg + 2u * (size_t)first;
-        a.n_jobs = cnt; a.bands = plan->fast_bands; a.strips = plan->fast_strips; a.uniform = 1u;
-        split_bands(fr::cov4_wg_waves(), cnt, plan->fast_bands, plan->fast_strips);
+    for (size_t i = 0; i < plan->parts.size(); ++i) {
+        // cov4_kernel / win1_kernel, one launch per (strip width, record slots) class that occurs in the plan
+        const fr_plan::Part &pt = plan->parts[i];
+        a.jobs = plan->d_jobs + pt.first;
+        a.job_seg = plan->d_job_seg + 2u * (size_t)pt.first;
+        a.n_jobs = pt.cnt; a.bands = pt.bands; a.strips = pt.strips; a.uniform = 1u;
+        a.strip_w = 16u << pt.wlog;
+        split_bands(fr::cov4_wg_waves(), pt.cnt, pt.bands, pt.strips);
         const int pm = plan->params.mode;
-        hipStream_t pst = (forked && part != big) ? ctx->aux : ctx->stream;
-        if (pm == FR_COVERAGE_U8 && plan->params.samples_per_axis == 4) HIP_TRY(fr::launch_cov4(a, rec_cap, pst));
-        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), rec_cap, pst));
+        hipStream_t pst = (forked && i != big) ? ctx->aux : ctx->stream;
+        if (plan->fast_ns > 1) HIP_TRY(fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, pst));
+        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, pst));
     }
     return FR_OK;
     };
@@ -656,6 +745,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     }
     if (rc_parts) return rc_parts;
     if (sdf) {
+        a.strip_w = plan->strip_w;
         a.jobs = plan->d_jobs;
         a.job_seg = plan->d_job_seg;
         a.n_jobs = plan->n_jobs;
@@ -839,8 +929,22 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
     gs.d_rec_count = reinterpret_cast<uint32_t *>(A0 + o_cnt); gs.d_recs = reinterpret_cast<fr::Rec *>(A0 + o_recs);
     fr_plan pl;
     pl.ctx = ctx; pl.gs = &gs; pl.n_jobs = 1; pl.n_fast = 0; pl.params = prm;
+    {
+        // the same per-job rule as fr_plan_create: the image takes win1_kernel (64- / 128- / 256-pixel strips by its
+        // own width) unless the glyph is too large for it
+        const FastRule rule = fast_rule(ctx, &prm);
+        std::vector<std::pair<int32_t, int32_t>> ev;
+        const int cls = fast_class(rule, w, h, ns, glyph_root_bound(points_xy, seg_p0.data(), 0, ns),
+                                   glyph_ray_bound(points_xy, seg_p0.data(), 0, ns, ev));
+        if (cls) {
+            uint32_t counts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            counts[cls - 1] = 1;
+            pl.n_fast = 1;
+            make_parts(&pl, &jb, counts, rule.ns);
+        }
+    }
     pl.d_jobs = reinterpret_cast<fr::Job *>(A0 + o_job); pl.d_job_seg = reinterpret_cast<uint32_t *>(A0 + o_jseg);
-    pl.d_large = reinterpret_cast<uint32_t *>(A0 + o_large); pl.n_large = ns > 128u ? 1u : 0u;
+    pl.d_large = reinterpret_cast<uint32_t *>(A0 + o_large); pl.n_large = (ns > 128u && !pl.n_fast) ? 1u : 0u;
     pl.max_w = w; pl.max_h = h; pl.pixels = (uint64_t)w * h; pl.need_cols = w; pl.need_rows = h;
     uint32_t sw = ((uint32_t)w + 15u) & ~15u;
     if (sw > ctx->strip_px) sw = ctx->strip_px;
@@ -1091,6 +1195,39 @@ int fr_atlas_layout(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyp
         if (page_of_job) page_of_job[i] = per_page ? (uint32_t)(i / per_page) : 0u;
     }
     if (n_pages) *n_pages = per_page ? (uint32_t)((n_glyphs + per_page - 1) / per_page) : (n_glyphs ? 1u : 0u);
+    return FR_OK;
+}
+
+// renderGlyph's own image per glyph (render_glyph.zig:13-19 through fr_render_glyph_dims), shelf-packed in input order
+int fr_atlas_layout_glyph_dims(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyph,
+                               const uint16_t *units_per_em, uint32_t n_upm, uint16_t font_size,
+                               uint32_t atlas_w, uint32_t align, fr_job *jobs_out, uint32_t *atlas_h)
+{
+    if (n_glyphs && (!boxes || !jobs_out)) return fail(FR_E_INVALID, "fr_atlas_layout_glyph_dims: NULL argument");
+    if (!units_per_em || (n_upm != 1 && n_upm != n_glyphs)) return fail(FR_E_INVALID, "units_per_em: one value or one per glyph");
+    if (atlas_w == 0 || font_size == 0) return fail(FR_E_INVALID, "atlas_w and font_size must be > 0");
+    if (align == 0) align = 1;
+    uint64_t x = 0, y = 0, shelf_h = 0;
+    for (uint32_t i = 0; i < n_glyphs; ++i) {
+        int16_t mn[2], mx[2];
+        uint16_t w, h;
+        float scale;
+        const int rc = fr_render_glyph_dims(boxes + 4 * (size_t)i, units_per_em[n_upm == 1 ? 0 : i], font_size, mn, mx, &w, &h, &scale);
+        if (rc) return rc;
+        if (w > atlas_w) return fail(FR_E_INVALID, "glyph %u is %u pixels wide, the atlas %u", i, (unsigned)w, atlas_w);
+        x = (x + align - 1) / align * align;
+        if (x + w > atlas_w) { x = 0; y += shelf_h; shelf_h = 0; }          // next shelf
+        if (y + h > 0xffffffffull) return fail(FR_E_UNSUPPORTED, "atlas taller than 2^32 pixels");
+        fr_job &jb = jobs_out[i];
+        jb.glyph = first_glyph + i;
+        jb.min_x = mn[0]; jb.max_y = mx[1];                                  // :26-27: sample (min_x + x, max_y - y)
+        jb.w = w; jb.h = h;
+        jb.out_x = (uint32_t)x; jb.out_y = (uint32_t)y;
+        jb.scale = scale;
+        x += w;
+        shelf_h = std::max<uint64_t>(shelf_h, h);
+    }
+    if (atlas_h) *atlas_h = (uint32_t)std::min<uint64_t>(y + shelf_h, 0xffffffffull);
     return FR_OK;
 }
 

@@ -29,6 +29,7 @@
 // windows of the row — then maps 16 counts to bytes at once.  Integer all the way: the result is the same
 // count k of inside samples per pixel, u8 = 16 k - [k > 8] = round_half_up(255 k / 16).
 #include "fr_c4.hpp"
+#include <cstdio>
 #include <type_traits>
 
 namespace fr {
@@ -74,15 +75,30 @@ __device__ __forceinline__ void c4_packed_sort(uint32_t (&d)[16])
 #ifdef FR_C4_STATS
 __device__ unsigned long long g_c4_stats[16];
 #endif
+// Timing-only ablation builds (`make ablate4`, tools/c4_ablate.sh: wrong output by construction, never shipped) cut the
+// kernel short at the C4_ABL_* points; their bodies live in fr_cov4_ablate.inc, which only those builds include.
+#ifdef FR_C4_ABLATE
+#include "fr_cov4_ablate.inc"
+#else
+#define C4_ABL_LAUNCH_ONLY()
+#define C4_ABL_JOB_ONLY()
+#define C4_ABL_SEGLOAD_ONLY()
+#define C4_ABL_SETUP_ONLY()
+#define C4_ABL_EVAL_ONLY()
+#define C4_ABL_SORT_ONLY()
+#define C4_ABL_KEEP(k) true
+#define C4_ABL_NODECODE 0
+#endif
 // LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
-template <int WLOG, int RPL>
+template <int WLOG, int RPL, int NS>
 struct C4Lds {
-    static constexpr uint32_t NCOL = (16u << WLOG) * 4u;                    // sample columns of a strip
+    static constexpr uint32_t NCOL = (16u << WLOG) * (uint32_t)NS;          // sample columns of a strip
+    static constexpr uint32_t PRB = 64u / (uint32_t)NS;                     // pixel rows of a wave band (64 sample rows)
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;         // padded cx table
     static constexpr uint32_t RCAP = 64u * RPL;                             // root records a workgroup keeps
     static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
     static constexpr uint32_t EROW = (16u << WLOG) + 16u;                   // bytes per pixel row of E (one 16-B pad)
-    static constexpr uint32_t E = 16u * EROW;
+    static constexpr uint32_t E = PRB * EROW;
     // walk buffers: lists [64][LSTRIDE] u16 | markers [PCAP] u16 | cy [64] f32 | cnt [64] u32 | roff [256] i16
     static constexpr uint32_t LISTS = 64u * C4_LSTRIDE * 2u;
     static constexpr uint32_t OFF_PAIRS = LISTS;
@@ -96,20 +112,36 @@ struct C4Lds {
     static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
 };
 
-// One workgroup (4 waves) = one cell (or one group of its wave bands, or one 256-px strip of it).
-// WLOG: strip width 16 << WLOG pixels (3: 128, 4: 256).  CAP: crossings a sample row keeps (8 / 16 / 32);
+// finished pixels of one 16-pixel window, clipped to the cell: the first m of the 16 bytes (m <= 0: none)
+__device__ __forceinline__ void c4_store_clip(unsigned char *dst, uint4 v, int m)
+{
+    if (m >= 16) { c4_store16(dst, v); return; }
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < m) dst[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+}
+
+// One workgroup (4 waves) = one cell (or one group of its wave bands, or one strip of it).  The cell may be ragged:
+// any width and height (renderGlyph sizes an image to the glyph's own box, render_glyph.zig:14-19) — the last strip
+// and the last band are computed whole and their stores are clipped to the cell.
+// WLOG: strip width 16 << WLOG pixels (2: 64, 3: 128, 4: 256).  CAP: crossings a sample row keeps (8 / 16 / 32);
 // fuller rows take the direct sum over the glyph's records.  RPL: root records per lane, 2, 4 or 8 — a workgroup
-// keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).
-template <int WLOG, int CAP, int RPL>
+// keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).  NS: samples per pixel axis,
+// 4 (16 samples per pixel) or 2 (4): a wave band is 64 sample rows = 64 / NS pixel rows.
+template <int WLOG, int CAP, int RPL, int NS>
 __global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
 void cov4_kernel(const RenderArgs A)
 {
-    using L = C4Lds<WLOG, RPL>;
+    using L = C4Lds<WLOG, RPL, NS>;
+    static_assert(NS == 4 || NS == 2, "samples per axis");
     constexpr uint32_t RCAP = L::RCAP;
     constexpr uint32_t NW = C4_WAVES;
     constexpr uint32_t SW = 16u << WLOG;            // strip width, pixels
-    constexpr uint32_t NCOL = SW * 4u;              // sample columns
+    constexpr uint32_t NCOL = SW * (uint32_t)NS;    // sample columns
     constexpr uint32_t NWIN = 1u << WLOG;           // 16-pixel windows per pixel row
+    constexpr uint32_t PRB = L::PRB;                // pixel rows per wave band
+    constexpr int LN = (NS == 4) ? 2 : 1;           // log2 NS
     extern __shared__ __align__(16) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -117,36 +149,26 @@ void cov4_kernel(const RenderArgs A)
     if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
     if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
     const uint32_t jidx = bid;
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 9
-    if (A.n_jobs != 0xffffffffu) return;                                                        // timing-only: the launch alone
-#endif
+    C4_ABL_LAUNCH_ONLY();
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * SW;
     const uint32_t band_first = bgrp * A.bands_per_wg;
-    if (band_first * 16u >= job.h || x0s >= job.w) return;                  // workgroup-uniform
-    const uint32_t band_end = min(band_first + A.bands_per_wg, job.h / 16u);
+    if (band_first * PRB >= job.h || x0s >= job.w) return;                  // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + PRB - 1u) / PRB);
+    const uint32_t wlim = min(SW, job.w - x0s);                             // pixels of this strip that lie in the cell
     const int phase = A.phase_center;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
-
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 10
-    if (A.n_jobs != 0xffffffffu) { if (job.w + seg0 + nseg == 0x7fffffffu) reinterpret_cast<uint8_t *>(A.out)[0] = 1; return; }   // timing-only: launch + job + segment range
-#endif
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 11
-    if (A.n_jobs != 0xffffffffu) {                                                              // timing-only: ... + my segment's points
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(A.seg_pts + 6u * (size_t)(seg0 + min(tid >> 1, nseg - 1u)));
-        if (w[0] + w[1] + w[2] + job.w == 0x7fffffffu) reinterpret_cast<uint8_t *>(A.out)[0] = 1;
-        return;
-    }
-#endif
+    C4_ABL_JOB_ONLY();
+    C4_ABL_SEGLOAD_ONLY();
     float *s_cxp = reinterpret_cast<float *>(smem);
     Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
     unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
 
-    const uint32_t rec_cnt = c4_setup<NW, RCAP, 4, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, NS, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
     const int32_t min_xs = job.min_x + (int32_t)x0s;
-    const float jscale = job.scale * 4.0f;
-    const float joff = (float)min_xs * 4.0f + (phase ? 0.5f : 0.0f) - 1.0f;
+    const float jscale = job.scale * (float)NS;
+    const float joff = (float)min_xs * (float)NS + (phase ? 0.5f : 0.0f) - 1.0f;
     const float ncolf = (float)NCOL;
     // every lane keeps the row ranges of its records in registers for all its bands: records RPL*lane ...
     // (consecutive, so the record index grows along the pair sequence and the marker decode is a max-scan)
@@ -169,16 +191,14 @@ void cov4_kernel(const RenderArgs A)
     int16_t *s_roff = reinterpret_cast<int16_t *>(wregion + L::OFF_ROFF);
     unsigned char *s_E = wregion;
 
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 5
-    if (A.n_jobs != 0xffffffffu) { if (rra[0] + rre[RPL > 1 ? 1 : 0] + rra[RPL > 1 ? RPL - 2 : 0] + rre[RPL - 1] == 0x12345u) s_wcnt[0] = 1u; return; }   // timing-only: set-up alone
-#endif
+    C4_ABL_SETUP_ONLY();
     for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
         const uint32_t band = band0 + wave;
         if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
-        const uint32_t y0 = band * 16u;
+        const uint32_t y0 = band * PRB;
         const uint32_t row_b0 = band * 64u;
         // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
-        const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane >> 2))) - sub_off((int)(lane & 3u), 4, phase)) / job.scale;
+        const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane >> LN))) - sub_off((int)(lane & (uint32_t)(NS - 1)), NS, phase)) / job.scale;
         uint16_t *mylist = s_lists + lane * C4_LSTRIDE;
         {
             const uint4 ones = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
@@ -239,11 +259,7 @@ void cov4_kernel(const RenderArgs A)
                 // current 64 are evaluated (an independent chain that fills the evaluation's wait states)
                 uint32_t k_cur = max(c4_wave_incl_max((uint32_t)s_pairs[lane]), carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 3
-                for (uint32_t p0 = 0; p0 < nhere && A.n_jobs == 0xffffffffu; p0 += 64u) {      // timing-only: pairs laid out, never evaluated
-#else
-                for (uint32_t p0 = 0; p0 < nhere; p0 += 64u) {
-#endif
+                for (uint32_t p0 = 0; p0 < nhere && C4_ABL_KEEP(3); p0 += 64u) {
                     const uint32_t pn = min(p0 + 64u + lane, (uint32_t)C4_PCAP - 1u);
                     const uint32_t s_next = c4_wave_incl_max((uint32_t)s_pairs[pn]);
                     {
@@ -251,7 +267,7 @@ void cov4_kernel(const RenderArgs A)
                         const bool livep = p < npairs;
                         // (a lane past the end decodes the last record and a row that may lie outside the band:
                         // it computes like the others and is kept from the table walk and the append)
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 7
+#if C4_ABL_NODECODE
                         const uint32_t row = (p + (k1 & 1u)) & 63u;                                 // timing-only: no dependent decode loads
                         const uint32_t raddr = L::CX + ((lane & 3u) + (A.n_jobs == 0xffffffffu ? k1 : 0u)) * (uint32_t)sizeof(Rec40);
 #else
@@ -323,17 +339,21 @@ void cov4_kernel(const RenderArgs A)
               }
             }
         }
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 4
-        if (A.n_jobs != 0xffffffffu) continue;                                                  // timing-only: set-up, layout and evaluation alone
-#endif
+        C4_ABL_EVAL_ONLY();
         const uint32_t cnt = s_cnt[lane];
         uint8_t *const out_band = reinterpret_cast<uint8_t *>(A.out) + ((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s;
         const uint32_t wx = lane & (NWIN - 1u);
+        // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
+        // (wave-uniform — a whole cell never takes the clipped stores)
+        const uint32_t hlim = min(PRB, job.h - y0);
+        const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < SW) | (hlim < PRB))) != 0;
         if (__ballot(cnt != 0u) == 0ull) {
             // no crossing on any of my 64 sample rows: every winding is 0 — store the band's background
-            for (uint32_t yl = lane >> WLOG; yl < 16u; yl += (64u >> WLOG)) {
+            for (uint32_t yl = lane >> WLOG; yl < PRB; yl += (64u >> WLOG)) {
                 const uint4 z = make_uint4(0, 0, 0, 0);
-                c4_store16(out_band + (size_t)yl * A.out_stride + 16u * wx, z);
+                unsigned char *dst = out_band + (size_t)yl * A.out_stride + 16u * wx;
+                if (!edge) c4_store16(dst, z);
+                else c4_store_clip(dst, z, yl < hlim ? (int)wlim - (int)(16u * wx) : 0);
             }
             c4_wave_lds_sync();
             continue;
@@ -386,9 +406,7 @@ void cov4_kernel(const RenderArgs A)
         }
 #endif
 
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 6
-        if (A.n_jobs != 0xffffffffu) { if (d[0] + d[3] + d[7] + d[15] + Hcur + maxcnt == 0x12345u) s_cnt[0] = 1u; continue; }   // timing-only: up to the sort
-#endif
+        C4_ABL_SORT_ONLY();
         // ---- E: every byte starts at the bias 16
         {
             uint4 *z = reinterpret_cast<uint4 *>(s_E);
@@ -401,28 +419,25 @@ void cov4_kernel(const RenderArgs A)
         c4_wave_lds_sync();
         // ---- toggles: right to left with the running winding; a crossing that changes zero <-> non-zero adds
         // its two differences to my pixel row's bytes
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 2
-        if (A.n_jobs == 0xffffffffu)                                                            // timing-only: no toggles
-#endif
-        {
-            unsigned char *erow = s_E + (lane >> 2) * L::EROW;
+        if (C4_ABL_KEEP(2)) {
+            unsigned char *erow = s_E + (lane >> LN) * L::EROW;
             int run = 0;
             bool zero = true;
             // toggles alternate (zero <-> non-zero), so -sigma of the next toggle is a register that flips:
-            // A = 255 * (-sigma), B = 4 * (-sigma); V = e0 + 256 e1 = -sigma (255 f + 4) = f A + B
-            int A255 = -255, B4 = -4, ns = -1;
+            // A = 255 * (-sigma), B = NS * (-sigma); V = e0 + 256 e1 = -sigma (255 f + NS) = f A + B
+            int A255 = -255, B4 = -NS, ns = -1;
             auto slot = [&](uint32_t dw, int o) {       // crossing (J << 2) | code in bits o .. o + 15 of dw
                 run += (int)((dw >> o) & 3u) - 1;
                 const bool z = run == 0;
                 if (z != zero) {
-                    const uint32_t nib = (dw >> (o + 2)) & 15u;             // (P & 3) << 2 | f,  P = J >> 2, f = J & 3
-                    const int V = __mul24((int)(nib & 3u), A255) + B4;
-                    const uint32_t sh = (dw >> (o + 1)) & 0x18u;            // 8 (P & 3)
-                    uint32_t *dwp = reinterpret_cast<uint32_t *>(erow + ((dw >> (o + 4)) & 0xffcu));
+                    const uint32_t nib = (dw >> (o + 2)) & (uint32_t)(4 * NS - 1);   // (P & 3) << LN | f,  P = J / NS, f = J % NS
+                    const int V = __mul24((int)(nib & (uint32_t)(NS - 1)), A255) + B4;
+                    const uint32_t sh = (dw >> (o + LN - 1)) & 0x18u;       // 8 (P & 3)
+                    uint32_t *dwp = reinterpret_cast<uint32_t *>(erow + ((dw >> (o + LN + 2)) & 0xffcu));
                     atomicAdd(dwp, (uint32_t)V << sh);
                     // the second difference of a pixel in byte 3 belongs to the next dword: e1 = -sigma f
-                    // there, 0 elsewhere — f if (P & 3) == 3, i.e. nib - 12 saturated at 0
-                    const uint32_t g3 = __builtin_elementwise_sub_sat(nib, 12u);
+                    // there, 0 elsewhere — f if (P & 3) == 3, i.e. nib - 3 NS saturated at 0
+                    const uint32_t g3 = __builtin_elementwise_sub_sat(nib, (uint32_t)(3 * NS));
                     atomicAdd(dwp + 1, (uint32_t)__mul24((int)g3, ns));
                     A255 = -A255; B4 = -B4; ns = -ns;
                 }
@@ -440,8 +455,8 @@ void cov4_kernel(const RenderArgs A)
 #pragma unroll
                 for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(d[j], 0);
             }
-            // the row's constant: 4 [w(0) != 0], into byte 0 of the pixel row
-            if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), 4u);
+            // the row's constant: NS [w(0) != 0], into byte 0 of the pixel row
+            if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), (uint32_t)NS);
         }
         if (__builtin_expect(ovf_rows != 0ull, 0)) {
             // ---- over-full sample rows (more than CAP crossings): the direct sum.  Every record of mine whose row
@@ -496,15 +511,23 @@ void cov4_kernel(const RenderArgs A)
                 }
                 const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
                 const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);   // everything right of my 16 columns
-                int cq[4];
+                constexpr int PPL = 16 / NS;                              // pixels of my 16 sample columns
+                int cq[PPL];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    cq[q] = (wl[4 * q] + right != 0) + (wl[4 * q + 1] + right != 0) + (wl[4 * q + 2] + right != 0) + (wl[4 * q + 3] + right != 0);
-                int prev = __shfl_up(cq[3], 1);
+                for (int q = 0; q < PPL; ++q) {
+                    cq[q] = 0;
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) cq[q] += (wl[NS * q + c] + right != 0);
+                }
+                int prev = __shfl_up(cq[PPL - 1], 1);
                 if (lane == 0) prev = 0;
-                const uint32_t val = (uint32_t)(cq[0] - prev) + ((uint32_t)(cq[1] - cq[0]) << 8) +
-                                     ((uint32_t)(cq[2] - cq[1]) << 16) + ((uint32_t)(cq[3] - cq[2]) << 24);
-                if (16u * lane < NCOL) atomicAdd(reinterpret_cast<uint32_t *>(s_E + (r >> 2) * L::EROW) + lane, val);
+#pragma unroll
+                for (int dq = 0; dq < PPL / 4; ++dq) {
+                    const int before = dq ? cq[4 * dq - 1] : prev;
+                    const uint32_t val = (uint32_t)(cq[4 * dq] - before) + ((uint32_t)(cq[4 * dq + 1] - cq[4 * dq]) << 8) +
+                                         ((uint32_t)(cq[4 * dq + 2] - cq[4 * dq + 1]) << 16) + ((uint32_t)(cq[4 * dq + 3] - cq[4 * dq + 2]) << 24);
+                    if (16u * lane < NCOL) atomicAdd(reinterpret_cast<uint32_t *>(s_E + (r >> LN) * L::EROW) + lane * (uint32_t)(PPL / 4) + (uint32_t)dq, val);
+                }
                 c4_wave_lds_sync();
             }
         }
@@ -512,11 +535,9 @@ void cov4_kernel(const RenderArgs A)
 
         // ---- windows: lane = one 16-pixel window of one pixel row; integrate, map, one 16-byte store
         constexpr uint32_t K1 = 0x01010101u;
-#if defined(FR_C4_ABLATE) && FR_C4_ABLATE == 1
-        if (A.n_jobs == 0xffffffffu)                                                            // timing-only: no windows, no stores
-#endif
+        if (C4_ABL_KEEP(1))
 #pragma unroll
-        for (uint32_t it = 0; it < (16u * NWIN) / 64u; ++it) {
+        for (uint32_t it = 0; it < (PRB * NWIN) / 64u; ++it) {
             const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
             const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
             // inclusive byte prefix inside each dword: bytes 16 (i + 1) + sums; back to a bias of 16 per byte
@@ -534,36 +555,39 @@ void cov4_kernel(const RenderArgs A)
                 inc += c4_dpp0<0x114>(inc);
                 inc += c4_dpp0<0x118>(inc);
             } else {
-                // 8 windows per pixel row: two pixel rows share a DPP row — keep the scan inside each half
+                // 8 (4) windows per pixel row: two (four) pixel rows share a DPP row — keep the scan inside each part
                 uint32_t s;
                 s = c4_dpp0<0x111>(inc); inc += (wx >= 1u) ? s : 0u;
                 s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
-                s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u;
+                if (WLOG == 3) { s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u; }
             }
-            const uint32_t cin = inc - T;                                   // in [0, 16]
+            const uint32_t cin = inc - T;                                   // in [0, NS^2]
             const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
             x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 16 + k, k = inside samples of the pixel
-            // u8 = 16 k - [k > 8] = round_half_up(255 k / 16), four pixels at once (see the header)
+            // u8 = round_half_up(255 k / NS^2) = 16 k - [k > 8] (NS = 4) / 64 k - [k > 2] (NS = 2), four pixels at once:
+            // (16 + k) << s leaves 2^(4 + s) too much in every byte — 0x01010100 (0x04040400) over the dword, mod 2^32
             auto map4 = [](uint32_t x) -> uint32_t {
-                const uint32_t t = ((x + 0x07070707u) >> 5) & 0x01010101u;
-                const uint32_t u = 0xfefeff00u - t;
                 uint32_t r;
-                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(r) : "v"(x), "v"(u));      // (x << 4) + u in one instruction
+                if (NS == 4) {
+                    const uint32_t t = ((x + 0x07070707u) >> 5) & 0x01010101u;
+                    const uint32_t u = 0xfefeff00u - t;
+                    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(r) : "v"(x), "v"(u));      // (x << 4) + u in one instruction
+                } else {
+                    const uint32_t t = ((x + 0x0d0d0d0du) >> 5) & 0x01010101u;
+                    const uint32_t u = 0xfbfbfc00u - t;
+                    asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(r) : "v"(x), "v"(u));
+                }
                 return r;
             };
             const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
-            c4_store16(out_band + (size_t)prow * A.out_stride + 16u * wx, v);
+            unsigned char *dst = out_band + (size_t)prow * A.out_stride + 16u * wx;
+            if (!edge) c4_store16(dst, v);
+            else c4_store_clip(dst, v, prow < hlim ? (int)wlim - (int)(16u * wx) : 0);
         }
         c4_wave_lds_sync();                        // E is the next band's list region
     }
 }
 
-size_t cov4_lds_bytes(int wlog, int rpl)
-{
-    if (rpl == 2) return wlog == 4 ? C4Lds<4, 2>::TOTAL : C4Lds<3, 2>::TOTAL;
-    if (rpl == 4) return wlog == 4 ? C4Lds<4, 4>::TOTAL : C4Lds<3, 4>::TOTAL;
-    return wlog == 4 ? C4Lds<4, 8>::TOTAL : C4Lds<3, 8>::TOTAL;
-}
 #ifdef FR_C4_STATS
 extern "C" int fr_debug_read_c4_stats(unsigned long long *out16, int reset)
 {
@@ -578,10 +602,18 @@ extern "C" int fr_debug_read_c4_stats(unsigned long long *out16, int reset)
 uint32_t cov4_wg_waves() { return C4_WAVES; }
 uint32_t cov4_max_segments() { return 384u; }     // (with 512 record slots; 256 for the smaller instances: fr_plan_create)
 
-template <int WLOG, int RPL>
-static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
+template <int WLOG, int RPL, int NS>
+static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
-    const size_t lds = C4Lds<WLOG, RPL>::TOTAL + a.lds_pad;
+    const size_t lds = C4Lds<WLOG, RPL, NS>::TOTAL + a.lds_pad;
+    // glyphs of <= 128 candidate roots (RPL == 2) all but never put more than 16 crossings on a sample row (a real font:
+    // 1 row in 100 000): their instance keeps 16 per row in registers — half the list to initialise, pull and sort, 5 %
+    // faster — and the rare fuller row takes the direct sum like any over-full row
+    const uint32_t kmax = (RPL == 2 && a.kmax > 16u) ? 16u : a.kmax;
+    const int cap = kmax <= 8 ? 8 : (kmax <= 16 ? 16 : 32);
+    // the instance as rocprofv3 names it
+    if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, %d, %d, %d>", WLOG, cap, RPL, NS);
+    if (!grid.x) return hipSuccess;                // (name only)
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {                   // (the 512-record instance; below that the default limit is enough)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -590,29 +622,34 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
         hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
         return hipGetLastError();
     };
-    // glyphs of <= 128 candidate roots (RPL == 2) all but never put more than 16 crossings on a sample row (a real font:
-    // 1 row in 100 000): their instance keeps 16 per row in registers — half the list to initialise, pull and sort, 5 %
-    // faster — and the rare fuller row takes the direct sum like any over-full row
-    const uint32_t kmax = (RPL == 2 && a.kmax > 16u) ? 16u : a.kmax;
-    if (kmax <= 8) return launch(cov4_kernel<WLOG, 8, RPL>);
-    if (kmax <= 16) return launch(cov4_kernel<WLOG, 16, RPL>);
-    return launch(cov4_kernel<WLOG, 32, RPL>);
+    if (cap == 8) return launch(cov4_kernel<WLOG, 8, RPL, NS>);
+    if (cap == 16) return launch(cov4_kernel<WLOG, 16, RPL, NS>);
+    return launch(cov4_kernel<WLOG, 32, RPL, NS>);
 }
 
-// jobs: uniform cells (w a multiple of strip_w in {128, 256}, h a multiple of 16 and <= 256), 4 x 4 samples,
-// every glyph with <= 256 segments and <= rec_cap (256 or 512) possible root records (checked by fr_plan_create)
-hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, hipStream_t stream)
+template <int WLOG, int NS>
+static hipError_t cov4_launch_rpl(const RenderArgs &a, uint32_t rec_cap, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
-    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
-    if (rec_cap <= 128u) {
-        if (a.strip_w == 256u) return cov4_launch_cap<4, 2>(a, grid, stream);
-        if (a.strip_w == 128u) return cov4_launch_cap<3, 2>(a, grid, stream);
-    } else if (rec_cap <= 256u) {
-        if (a.strip_w == 256u) return cov4_launch_cap<4, 4>(a, grid, stream);
-        if (a.strip_w == 128u) return cov4_launch_cap<3, 4>(a, grid, stream);
-    } else {
-        if (a.strip_w == 256u) return cov4_launch_cap<4, 8>(a, grid, stream);
-        if (a.strip_w == 128u) return cov4_launch_cap<3, 8>(a, grid, stream);
+    if (rec_cap <= 128u) return cov4_launch_cap<WLOG, 2, NS>(a, grid, stream, name, name_cap);
+    if (rec_cap <= 256u) return cov4_launch_cap<WLOG, 4, NS>(a, grid, stream, name, name_cap);
+    return cov4_launch_cap<WLOG, 8, NS>(a, grid, stream, name, name_cap);
+}
+
+// jobs: cells of any size up to 2048 / ns sample rows (strips of a.strip_w in {64, 128, 256} pixels, wave bands of 64 / ns
+// pixel rows; the last of each may be partial), ns x ns samples (ns in {2, 4}), every glyph with <= 384 segments and
+// <= rec_cap (128, 256 or 512) possible root records (checked by fr_plan_create).  launch = false: only name the
+// instance (as rocprofv3 prints it) into `name`.
+hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, int ns, hipStream_t stream, bool launch, char *name, size_t name_cap)
+{
+    const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);
+    if (ns == 4) {
+        if (a.strip_w == 256u) return cov4_launch_rpl<4, 4>(a, rec_cap, grid, stream, name, name_cap);
+        if (a.strip_w == 128u) return cov4_launch_rpl<3, 4>(a, rec_cap, grid, stream, name, name_cap);
+        if (a.strip_w == 64u) return cov4_launch_rpl<2, 4>(a, rec_cap, grid, stream, name, name_cap);
+    } else if (ns == 2) {
+        if (a.strip_w == 256u) return cov4_launch_rpl<4, 2>(a, rec_cap, grid, stream, name, name_cap);
+        if (a.strip_w == 128u) return cov4_launch_rpl<3, 2>(a, rec_cap, grid, stream, name, name_cap);
+        if (a.strip_w == 64u) return cov4_launch_rpl<2, 2>(a, rec_cap, grid, stream, name, name_cap);
     }
     return hipErrorInvalidValue;
 }

@@ -30,6 +30,7 @@
 // the direct sum over records (same integers, slower), inside the kernel.  DESIGN.md §3-§4 has the
 // arguments and the measurements.
 #include "fr_records.hpp"
+#include <cstdio>
 
 namespace fr {
 
@@ -989,8 +990,10 @@ void render_lds_plan(uint32_t strip_w, int n, int mode, uint32_t cap, uint32_t *
 }
 
 template <int MODE, int N, int CAP, int WLOG>
-static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
+static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
+    if (name) snprintf(name, name_cap, "fr::render_kernel<%d, %d, %d, %d>", MODE, N, CAP, WLOG);   // as rocprofv3 names the instance
+    if (!grid.x) return hipSuccess;                     // (name only)
     size_t lds;
     render_lds_plan(a.strip_w, N, MODE, CAP, &a.nwin_log, &a.lds_region, &a.lds_rec_bytes, &a.lds_wave_bytes, &a.lds_tail, &lds);
     lds += a.lds_pad;
@@ -1007,35 +1010,36 @@ static hipError_t launch_one(RenderArgs a, dim3 grid, hipStream_t stream)
 }
 
 template <int MODE, int N, int WLOG>
-static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream)
+static hipError_t launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
-    if (a.kmax <= 8) return launch_one<MODE, N, 8, WLOG>(a, grid, stream);
-    if (a.kmax <= 16) return launch_one<MODE, N, 16, WLOG>(a, grid, stream);
-    return launch_one<MODE, N, 32, WLOG>(a, grid, stream);
+    if (a.kmax <= 8) return launch_one<MODE, N, 8, WLOG>(a, grid, stream, name, name_cap);
+    if (a.kmax <= 16) return launch_one<MODE, N, 16, WLOG>(a, grid, stream, name, name_cap);
+    return launch_one<MODE, N, 32, WLOG>(a, grid, stream, name, name_cap);
 }
 
 uint32_t render_wg_waves() { return NW; }
 
-hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t stream)
+// launch = false: only name the instance (as rocprofv3 prints it) into `name`
+hipError_t launch_render(const RenderArgs &a, int mode, int n, hipStream_t stream, bool launch, char *name, size_t name_cap)
 {
-    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
+    const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);
     if (a.strip_w == 0 || a.strip_w > 256u || (a.strip_w & 15u)) return hipErrorInvalidValue;
     if (mode == MODE_COVERAGE_U8) {
-        if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream);
-        if (n == 2) return launch_cap<MODE_COVERAGE_U8, 2, -1>(a, grid, stream);
+        if (n == 1) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream, name, name_cap);
+        if (n == 2) return launch_cap<MODE_COVERAGE_U8, 2, -1>(a, grid, stream, name, name_cap);
         if (n == 4) {
             // uniform plans of 256- / 128-pixel strips (atlas cells) take the specialised instances
-            if (a.uniform && a.strip_w == 256u) return launch_cap<MODE_COVERAGE_U8, 4, 4>(a, grid, stream);
-            if (a.uniform && a.strip_w == 128u) return launch_cap<MODE_COVERAGE_U8, 4, 3>(a, grid, stream);
-            return launch_cap<MODE_COVERAGE_U8, 4, -1>(a, grid, stream);
+            if (a.uniform && a.strip_w == 256u) return launch_cap<MODE_COVERAGE_U8, 4, 4>(a, grid, stream, name, name_cap);
+            if (a.uniform && a.strip_w == 128u) return launch_cap<MODE_COVERAGE_U8, 4, 3>(a, grid, stream, name, name_cap);
+            return launch_cap<MODE_COVERAGE_U8, 4, -1>(a, grid, stream, name, name_cap);
         }
         return hipErrorInvalidValue;
     }
     if (n != 1) return hipErrorInvalidValue;
-    if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1, -1>(a, grid, stream);
-    if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1, -1>(a, grid, stream);
+    if (mode == MODE_WINDING_I16) return launch_cap<MODE_WINDING_I16, 1, -1>(a, grid, stream, name, name_cap);
+    if (mode == MODE_GRAY_DEBUG) return launch_cap<MODE_GRAY_DEBUG, 1, -1>(a, grid, stream, name, name_cap);
     // winding != 0 ? 255 : 0 is exactly the 1-sample coverage (round_half_up(255 k / 1), k in {0, 1})
-    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream);
+    if (mode == MODE_MASK_NONZERO) return launch_cap<MODE_COVERAGE_U8, 1, -1>(a, grid, stream, name, name_cap);
     return hipErrorInvalidValue;
 }
 

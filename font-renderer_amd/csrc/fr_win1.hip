@@ -14,6 +14,7 @@
 // the direct path — 16-bit differences, suffix scan, pixels written from there.  No lists, no sort, no toggles:
 // per 4 KB of gray output about half the vector instructions of cov4_kernel's 16-sample pixel.
 #include "fr_c4.hpp"
+#include <cstdio>
 
 namespace fr {
 
@@ -47,6 +48,24 @@ __device__ __forceinline__ uint32_t w1_gray(int w)
     return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// the first m of a window's 16 pixels (m <= 0: none), ESZ bytes each: a (and b, the second half of 16 int16 values)
+template <uint32_t ESZ>
+__device__ __forceinline__ void w1_store_clip(unsigned char *dst, uint4 a, uint4 b, int m)
+{
+    if (m >= 16) {
+        if (ESZ == 2u) { __builtin_memcpy(dst, &a, 16); __builtin_memcpy(dst + 16, &b, 16); }
+        else c4_store16(dst, a);
+        return;
+    }
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i >= m) continue;
+        if (ESZ == 2u) reinterpret_cast<uint16_t *>(dst)[i] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+        else dst[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
 template <int WLOG, int MODE, int RPL>
 __global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
 void win1_kernel(const RenderArgs A)
@@ -69,7 +88,8 @@ void win1_kernel(const RenderArgs A)
     const uint32_t x0s = strip * NCOL;
     const uint32_t band_first = bgrp * A.bands_per_wg;                      // bands of 16 pixel rows
     if (band_first * W1_ROWS >= job.h || x0s >= job.w) return;             // workgroup-uniform
-    const uint32_t band_end = min(band_first + A.bands_per_wg, job.h / W1_ROWS);
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + W1_ROWS - 1u) / W1_ROWS);
+    const uint32_t wlim = min(NCOL, job.w - x0s);                           // pixels of this strip that lie in the cell
     const int phase = A.phase_center;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
 
@@ -219,13 +239,18 @@ void win1_kernel(const RenderArgs A)
         unsigned char *const out_band = reinterpret_cast<unsigned char *>(A.out) +
                                         (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
         const size_t row_bytes = (size_t)A.out_stride * ESZ;
+        // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
+        // (wave-uniform — a whole cell never takes the clipped stores)
+        const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
+        const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < NCOL) | (hlim < (uint32_t)W1_ROWS))) != 0;
         if ((__ballot(cnt != 0u) & 0xffffull) == 0ull) {
             // no crossing on any of my 16 rows: every winding is 0
             const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
             const uint4 v = make_uint4(bg, bg, bg, bg);
             for (uint32_t yl = lane >> WLOG; yl < W1_ROWS; yl += (64u >> WLOG)) {
                 unsigned char *dst = out_band + (size_t)yl * row_bytes + 16u * ESZ * wx;
-                if (ESZ == 2u) { __builtin_memcpy(dst, &v, 16); __builtin_memcpy(dst + 16, &v, 16); }
+                if (edge) w1_store_clip<ESZ>(dst, v, v, yl < hlim ? (int)wlim - (int)(16u * wx) : 0);
+                else if (ESZ == 2u) { __builtin_memcpy(dst, &v, 16); __builtin_memcpy(dst + 16, &v, 16); }
                 else c4_store16(dst, v);
             }
             c4_wave_lds_sync();
@@ -281,11 +306,13 @@ void win1_kernel(const RenderArgs A)
                 }
                 const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
                 const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);
-                if (16u * lane < NCOL) {
+                if (16u * lane < wlim && r < hlim) {
                     unsigned char *dst = out_band + (size_t)r * row_bytes + 16u * ESZ * lane;
+                    const int mlim = (int)wlim - (int)(16u * lane);
 #pragma unroll
                     for (int cc = 0; cc < 16; ++cc) {
                         const int w = wl[cc] + right;
+                        if (cc >= mlim) continue;
                         if (MODE == MODE1_WINDING_I16) reinterpret_cast<int16_t *>(dst)[cc] = (int16_t)w;
                         else dst[cc] = (unsigned char)((MODE == MODE1_GRAY_DEBUG) ? w1_gray(w) : (w != 0 ? 255u : 0u));
                     }
@@ -317,7 +344,7 @@ void win1_kernel(const RenderArgs A)
                 uint32_t s;
                 s = c4_dpp0<0x111>(inc); inc += (wx >= 1u) ? s : 0u;
                 s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
-                s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u;
+                if (WLOG == 3) { s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u; }
             }
             const int w0 = (int)s_cnt[prow] >> 16;                           // w(0) of my pixel row
             const uint32_t cin = inc - T + 32u + (uint32_t)w0;              // winding entering my window, + 32: in [1, 63]
@@ -326,6 +353,7 @@ void win1_kernel(const RenderArgs A)
             const uint32_t p0 = x0, p1 = x1, p2 = x2, p3 = x3;              // (pixel order: byte x of the row is pixel x)
             if ((ovf_rows >> prow) & 1u) continue;                          // stored by the direct path above
             unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
+            const int mclip = prow < hlim ? (int)wlim - (int)(16u * wx) : 0;   // (edge only) pixels of my window inside the cell
             if (MODE == MODE1_MASK) {
                 auto m4 = [](uint32_t x) -> uint32_t {
                     const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
@@ -333,7 +361,7 @@ void win1_kernel(const RenderArgs A)
                     return nz | (nz - (nz >> 7));                           // 0x80 -> 0xff
                 };
                 const uint4 v = make_uint4(m4(p0), m4(p1), m4(p2), m4(p3));
-                c4_store16(dst, v);
+                if (edge) w1_store_clip<1u>(dst, v, v, mclip); else c4_store16(dst, v);
             } else if (MODE == MODE1_GRAY_DEBUG) {
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 auto g2 = [](uint32_t h) -> uint32_t {                      // two 16-bit lanes holding 96 + w
@@ -352,7 +380,7 @@ void win1_kernel(const RenderArgs A)
                 uint4 v;
                 if (__builtin_expect(__ballot(!plain) == 0ull, 1)) v = make_uint4(y0 * 20u, y1 * 20u, y2 * 20u, y3 * 20u);
                 else v = make_uint4(g4(p0), g4(p1), g4(p2), g4(p3));
-                c4_store16(dst, v);
+                if (edge) w1_store_clip<1u>(dst, v, v, mclip); else c4_store16(dst, v);
             } else {
                 typedef short i16x2 __attribute__((ext_vector_type(2)));
                 auto w2 = [](uint32_t h) -> uint32_t {
@@ -370,8 +398,8 @@ void win1_kernel(const RenderArgs A)
                 const uint4 va = make_uint4(o[0], o[1], o[2], o[3]), vb = make_uint4(o[4], o[5], o[6], o[7]);
                 // (two plain stores: each covers every other 16 bytes of the row, which the streaming hint would send to
                 // memory as half-written sectors — measured 2.6 x slower)
-                __builtin_memcpy(dst, &va, 16);
-                __builtin_memcpy(dst + 16, &vb, 16);
+                if (edge) w1_store_clip<2u>(dst, va, vb, mclip);
+                else { __builtin_memcpy(dst, &va, 16); __builtin_memcpy(dst + 16, &vb, 16); }
             }
         }
         c4_wave_lds_sync();                        // E is re-initialised by the next band
@@ -381,9 +409,11 @@ void win1_kernel(const RenderArgs A)
 uint32_t win1_band_rows() { return W1_ROWS; }
 
 template <int WLOG, int RPL>
-static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hipStream_t stream)
+static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
     const size_t lds = W1Lds<WLOG, RPL>::TOTAL + a.lds_pad;
+    if (name) snprintf(name, name_cap, "fr::win1_kernel<%d, %d, %d>", WLOG, mode, RPL);      // as rocprofv3 names the instance
+    if (!grid.x) return hipSuccess;               // (name only)
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -397,21 +427,23 @@ static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hip
     return launch(win1_kernel<WLOG, MODE1_MASK, RPL>);
 }
 
-// jobs: uniform cells (w a multiple of strip_w in {128, 256}, h a multiple of 16 and <= 1024), one sample per pixel,
-// glyphs with <= 256 segments and <= rec_cap possible root records.  mode: 0 winding_i16, 1 gray_debug, 2 mask
-hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream)
+template <int WLOG>
+static hipError_t win1_launch_rpl(const RenderArgs &a, int mode, uint32_t rec_cap, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
-    const dim3 grid((uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips));
-    if (rec_cap <= 128u) {
-        if (a.strip_w == 256u) return win1_launch_mode<4, 2>(a, mode, grid, stream);
-        if (a.strip_w == 128u) return win1_launch_mode<3, 2>(a, mode, grid, stream);
-    } else if (rec_cap <= 256u) {
-        if (a.strip_w == 256u) return win1_launch_mode<4, 4>(a, mode, grid, stream);
-        if (a.strip_w == 128u) return win1_launch_mode<3, 4>(a, mode, grid, stream);
-    } else {
-        if (a.strip_w == 256u) return win1_launch_mode<4, 8>(a, mode, grid, stream);
-        if (a.strip_w == 128u) return win1_launch_mode<3, 8>(a, mode, grid, stream);
-    }
+    if (rec_cap <= 128u) return win1_launch_mode<WLOG, 2>(a, mode, grid, stream, name, name_cap);
+    if (rec_cap <= 256u) return win1_launch_mode<WLOG, 4>(a, mode, grid, stream, name, name_cap);
+    return win1_launch_mode<WLOG, 8>(a, mode, grid, stream, name, name_cap);
+}
+
+// jobs: cells of any size up to 2048 rows (strips of a.strip_w in {64, 128, 256} pixels and bands of 16 rows; the last of
+// each may be partial), one sample per pixel, glyphs with <= 384 segments and <= rec_cap possible root records.
+// mode: 0 winding_i16, 1 gray_debug, 2 mask.  launch = false: only name the instance (as rocprofv3 prints it).
+hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream, bool launch, char *name, size_t name_cap)
+{
+    const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);
+    if (a.strip_w == 256u) return win1_launch_rpl<4>(a, mode, rec_cap, grid, stream, name, name_cap);
+    if (a.strip_w == 128u) return win1_launch_rpl<3>(a, mode, rec_cap, grid, stream, name, name_cap);
+    if (a.strip_w == 64u) return win1_launch_rpl<2>(a, mode, rec_cap, grid, stream, name, name_cap);
     return hipErrorInvalidValue;
 }
 

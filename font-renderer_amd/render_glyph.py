@@ -129,6 +129,12 @@ class Plan:
         L.check(self.ctx._lib.fr_plan_stats(self._h, C.byref(a), C.byref(b)))
         return {"jobs_cov4": a.value, "jobs_general": b.value}
 
+    def describe(self) -> str:
+        """the kernel instances one render launches, as rocprofv3 names them, with job counts"""
+        buf = C.create_string_buffer(1024)
+        L.check(self.ctx._lib.fr_plan_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def render(self, out_dev_ptr: int, out_stride: int, out_rows: int) -> None:
         """asynchronous on the context's stream; out_dev_ptr is a DEVICE address"""
         L.check(self.ctx._lib.fr_plan_render(self._h, C.c_void_p(out_dev_ptr), out_stride, out_rows))

@@ -92,7 +92,8 @@ typedef struct fr_plan fr_plan;
 /* ---- library / context -------------------------------------------------- */
 int fr_abi_version(void);
 const char *fr_last_error(void);
-/* a string that changes whenever a kernel of the hot path does (profiles/traffic.json is keyed by it) */
+/* a string that changes whenever a source file of the library does: "r03-" + the first 12 hex digits of the SHA-256 of
+ * csrc's sources, computed by the Makefile at build time (profiles/traffic.json is keyed by it) */
 const char *fr_build_id(void);
 
 /* device: HIP device ordinal.  hip_stream: a hipStream_t to launch on (e.g. the
@@ -102,7 +103,8 @@ void fr_ctx_destroy(fr_ctx *ctx);
 int fr_ctx_sync(fr_ctx *ctx);
 /* tuning / test knobs: "kmax" (crossings kept per sample row, in registers, before the
  * exact direct-sum fallback: rounded up to 8, 16 or 32; default 32), "strip_px" (column
- * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip),
+ * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip; the fast kernels use
+ * the largest of 64 / 128 / 256 that does not exceed it),
  * "cov4" (0: every job takes the general kernel), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
  * every pixel — the culls are exact, this is how the tests show it), "zero_copy" (1: fr_render_glyph renders small
  * glyphs straight from / into pinned host memory; measured no faster, off by default), "overlap" (0: a plan that
@@ -146,10 +148,15 @@ int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_r
 /* same, bracketed by HIP events on the launch stream; synchronous; *ms = kernel time */
 int fr_plan_render_timed(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows, float *ms);
 uint64_t fr_plan_pixels(const fr_plan *plan);   /* sum of w*h over the jobs */
-/* how the plan's jobs are split between the two render kernels (the decision is per job): cov4_kernel
- * (16-sample coverage of cells that are whole 128- / 256-pixel strips and 16-row bands, <= 256 pixels tall,
- * glyphs of <= 256 segments) and the general render_kernel (everything else)                          */
+/* how the plan's jobs are split between the render kernels (the decision is per job): the fast kernels — cov4_kernel
+ * (4 x 4 or 2 x 2 samples) / win1_kernel (one sample per pixel) — take cells of ANY width and height up to 2048 sample
+ * rows (renderGlyph's own image sizes, render_glyph.zig:14-19, included: strips of 64 / 128 / 256 pixels chosen from
+ * the job's width, stores clipped at the cell's border) of glyphs with <= 384 segments; the general render_kernel takes
+ * everything else                                                                                              */
 int fr_plan_stats(const fr_plan *plan, uint32_t *n_jobs_cov4, uint32_t *n_jobs_general);
+/* the kernel instances one render of the plan launches, as rocprofv3 --kernel-trace names them, each with its job
+ * count: "fr::cov4_kernel<4, 32, 4, 4> x20992; fr::render_kernel<3, 4, 32, -1> x3" (NUL-terminated, truncated to cap) */
+int fr_plan_describe(const fr_plan *plan, char *buf, size_t cap);
 
 /* One-shot: plan + render + copy back.  out_host: HOST buffer (caller-allocated,
  * e.g. Image.Gray.data / Image.Winding.data from the Zig allocator).  Synchronous.  */
@@ -220,6 +227,15 @@ int fr_atlas_layout(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyp
                     const uint16_t *units_per_em, uint32_t n_upm, uint16_t font_size,
                     uint32_t cell, uint32_t cols, uint32_t rows_per_page,
                     fr_job *jobs_out, uint32_t *page_of_job, uint32_t *n_pages);
+
+/* The reference's own product shape in batch: glyph i gets exactly the image renderGlyph would allocate for it —
+ * fr_render_glyph_dims' W x H, pixel (0,0) at (min_x, max_y) (render_glyph.zig:13-19, :26-27) — shelf-packed in input
+ * order into an atlas `atlas_w` elements wide: left to right, out_x rounded up to a multiple of `align` (1: tight),
+ * a new shelf when the next image does not fit; *atlas_h (if not NULL) receives the rows used.  Every job's bytes are
+ * what fr_render_glyph writes for that glyph (tests).                                                          */
+int fr_atlas_layout_glyph_dims(const int16_t *boxes, uint32_t n_glyphs, uint32_t first_glyph,
+                               const uint16_t *units_per_em, uint32_t n_upm, uint16_t font_size,
+                               uint32_t atlas_w, uint32_t align, fr_job *jobs_out, uint32_t *atlas_h);
 
 /* ---- multi-GPU assembly (optional; SURVEY section 8e: "optional final assembly: all-gather of row bands") --------
  * The hot path needs no collective: every rank renders its own glyph range into its own band.  When one rank (or all)

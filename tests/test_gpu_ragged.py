@@ -1,0 +1,156 @@
+"""GPU suite, round 3: the reference's own product shape in batch.
+
+renderGlyph sizes every image to the glyph's own box (render_glyph.zig:14-19: 47 x 45 for STIX 'A' at 64).  These tests
+put such ragged cells — any width, any height, unaligned destinations — through the fast kernels (cov4_kernel with
+4 x 4 and 2 x 2 samples, win1_kernel with one) and compare with the oracle byte for byte, including the bytes AROUND
+every cell (the clipped stores must not touch them) and the kernel split the plan reports."""
+import numpy as np
+import pytest
+
+import font_renderer_amd as fr
+import oracle_lib as O
+from font_renderer_amd import render_glyph as rg
+from font_renderer_amd.atlas import atlas_shape, cell_jobs, glyph_dims_jobs
+from font_renderer_amd.glyph import GlyphSet
+from font_renderer_amd.synth import comb_glyph, stroke_glyphset, synth_glyphset
+
+pytestmark = pytest.mark.gpu
+
+ONE = [(fr.FR_WINDING_I16, O.WINDING_I16, 1, False), (fr.FR_GRAY_DEBUG, O.GRAY_DEBUG, 1, False), (fr.FR_MASK_NONZERO, O.MASK_NONZERO, 1, False)]
+COV = [(fr.FR_COVERAGE_U8, O.COVERAGE_U8, n, c) for n in (1, 2, 4) for c in (False, True)]
+
+
+def _both(ctx, oracle, gs, jobs, mode, omode, shape, n, center, dgs, expect_general=0, want_in_describe=()):
+    dt = np.int16 if mode == fr.FR_WINDING_I16 else np.uint8
+    got = np.full(shape, 0x5b, dt)
+    ref = np.full(shape, 0x5b, dt)
+    phase = fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER
+    plan = fr.Plan(dgs, jobs, mode, n, phase)
+    st, desc = plan.stats(), plan.describe()
+    plan.close()
+    assert st["jobs_general"] == expect_general and st["jobs_cov4"] == len(jobs) - expect_general, (st, desc)
+    for w in want_in_describe:
+        assert w in desc, (w, desc)
+    rg.render_batch(dgs, jobs, mode, got, n, phase)
+    oracle.render_batch(gs, jobs, omode, ref, n, center, 16)
+    return got, ref, desc
+
+
+@pytest.mark.parametrize("font_size", [24, 64, 150])
+def test_renderglyph_dims_batch_takes_the_fast_kernels(ctx, oracle, ascii_set, font_size):
+    """190 real glyphs, each at exactly renderGlyph's image size (render_glyph.zig:13-19), shelf-packed tight (unaligned
+    out_x, a stride that is no multiple of 16): every mode == the oracle, nothing on the general kernel, the 64-pixel
+    strip instance in use for the small sizes; the gray job bytes == what fr_render_glyph returns for the glyph."""
+    gs = ascii_set.gs
+    jobs, H = glyph_dims_jobs(gs, font_size, ascii_set.g_upm, 1021)
+    assert len(jobs) == len(gs) and H > 0
+    i = ascii_set.find("STIX", "A")
+    if font_size == 64:
+        assert (int(jobs["w"][i]), int(jobs["h"][i])) == (47, 45)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    for mode, omode, n, center in ONE + COV:
+        fast = "win1_kernel" if n == 1 else "cov4_kernel"
+        want = [f"fr::{fast}<2, "] if font_size <= 64 else [f"fr::{fast}<3, ", f"fr::{fast}<4, "]
+        got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, (H + 3, 1021), n, center, dgs, 0, want)
+        assert np.array_equal(got, ref), (mode, n, center, desc)
+        if mode == fr.FR_GRAY_DEBUG:
+            assert (ref != 0x5b).any()
+            for k in (i, 3, 77, 150):
+                g = ascii_set.glyph(k)
+                im = fr.renderGlyph(g, fr.FontInformation(int(ascii_set.g_upm[k])), font_size, ctx=ctx)
+                j = jobs[k]
+                assert (im.width, im.height) == (int(j["w"]), int(j["h"]))
+                assert np.array_equal(im.as_2d(), got[j["out_y"]:j["out_y"] + j["h"], j["out_x"]:j["out_x"] + j["w"]])
+    dgs.close()
+
+
+def test_ragged_cells_unaligned_output_on_the_fast_kernels(ctx, oracle, ascii_set):
+    """the generator of test_ragged_cells_unaligned_output (odd sizes 1..69 x 1..299, unaligned destinations, arbitrary
+    origins and scales), now asserting the split: every job on cov4_kernel / win1_kernel"""
+    gs = ascii_set.gs
+    rows = []
+    rng = np.random.default_rng(3)
+    x = 1
+    for gi in rng.integers(0, len(ascii_set), 12):
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+        s = np.float32(rng.integers(8, 120)) / np.float32(ascii_set.g_upm[gi])
+        rows.append((int(gi), int(rng.integers(-20, 5)), int(rng.integers(20, 90)), w, h, x, int(rng.integers(0, 9)), s))
+        x += w + int(rng.integers(0, 3))
+    # + widths around the strip widths and heights around the band heights
+    for w, h in ((63, 15), (64, 16), (65, 17), (127, 31), (128, 33), (129, 47), (255, 48), (256, 49), (257, 5), (300, 70), (16, 1), (1, 64)):
+        gi = int(rng.integers(0, len(ascii_set)))
+        s = np.float32(rng.integers(30, 300)) / np.float32(ascii_set.g_upm[gi])
+        rows.append((gi, int(rng.integers(-10, 5)), int(rng.integers(10, 200)), w, h, x, int(rng.integers(0, 5)), s))
+        x += w + int(rng.integers(0, 3))
+    jobs = rg.make_jobs(rows)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    for mode, omode, n, center in ONE + COV:
+        got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, (311, x + 5), n, center, dgs)
+        assert np.array_equal(got, ref), (mode, n, center, desc)
+    dgs.close()
+
+
+@pytest.mark.parametrize("segs,cell", [(32, 128), (128, 256), (200, 96), (64, 50)])
+def test_two_by_two_samples_on_cov4(ctx, oracle, segs, cell):
+    """n = 2 (4 samples per pixel) on cov4_kernel<.., 2>: synthetic and stroke-dense glyphs, both phases"""
+    for make, first in ((synth_glyphset, 700), (stroke_glyphset, 900)):
+        gs = make(6, segs, first_index=first)
+        jobs = cell_jobs(gs, cell, cell, 2048, 3)
+        dgs = fr.DeviceGlyphSet(ctx, gs)
+        for center in (False, True):
+            got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, O.COVERAGE_U8, atlas_shape(len(gs), cell, 3), 2, center, dgs, 0,
+                                   ["fr::cov4_kernel<", ", 2> x"])
+            assert np.array_equal(got, ref), (segs, cell, center, desc)
+            assert set(np.unique(ref)) <= {0x5b, 0, 64, 128, 191, 255}
+        dgs.close()
+
+
+def test_two_by_two_overfull_rows_and_tall_cells(ctx, oracle):
+    """n = 2: combs whose rays meet 80 / 12 crossings with 8 / 16 / 32 kept per sample row (the direct sum inside
+    cov4_kernel<.., 2>), and a 200 x 1000 cell (2000 sample rows: the 12-bit row fields' limit is 2048)"""
+    gl = [comb_glyph(40), comb_glyph(6)]
+    gs = GlyphSet(gl)
+    jobs = cell_jobs(gs, 160, 150, 2048, 2)
+    ref = np.full((160, 320), 0x5b, np.uint8)
+    oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 2, True, 16)
+    for kmax in (8, 16, 32):
+        try:
+            ctx.set_option("kmax", kmax)
+            dgs = fr.DeviceGlyphSet(ctx, gs)
+            plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 2, fr.FR_SAMPLE_CENTER)
+            assert plan.stats()["jobs_general"] == 0
+            plan.close()
+            got = np.full_like(ref, 0x5b)
+            rg.render_batch(dgs, jobs, fr.FR_COVERAGE_U8, got, 2, fr.FR_SAMPLE_CENTER)
+            dgs.close()
+        finally:
+            ctx.set_option("kmax", 32)
+        assert np.array_equal(got, ref), kmax
+    gs = synth_glyphset(1, 96, first_index=4141)
+    tall = rg.make_jobs([(0, int(np.floor(gs.boxes[0][0] * 0.1)) - 3, int(np.ceil(gs.boxes[0][3] * 0.5)) + 8, 200, 1000, 3, 1, np.float32(0.5))])
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    got, ref, desc = _both(ctx, oracle, gs, tall, fr.FR_COVERAGE_U8, O.COVERAGE_U8, (1003, 210), 2, False, dgs)
+    dgs.close()
+    assert np.array_equal(got, ref) and (ref == 255).any()
+
+
+def test_strip_px_option_bounds_the_fast_strips(ctx, oracle, ascii_set):
+    """strip_px = 64 / 128: wide cells walk more, narrower strips on the fast kernels; below 64 they take the general kernel"""
+    gs = ascii_set.gs
+    jobs, H = glyph_dims_jobs(gs, 200, ascii_set.g_upm, 2048, n_glyphs=40)
+    ref = np.full((H, 2048), 0x5b, np.uint8)
+    oracle.render_batch(gs, jobs, O.COVERAGE_U8, ref, 4, True, 16)
+    for px, inst in ((64, "cov4_kernel<2"), (128, "cov4_kernel<3"), (48, "render_kernel")):
+        try:
+            ctx.set_option("strip_px", px)
+            dgs = fr.DeviceGlyphSet(ctx, gs)
+            plan = fr.Plan(dgs, jobs, fr.FR_COVERAGE_U8, 4, fr.FR_SAMPLE_CENTER)
+            desc = plan.describe()
+            plan.close()
+            got = np.full_like(ref, 0x5b)
+            rg.render_batch(dgs, jobs, fr.FR_COVERAGE_U8, got, 4, fr.FR_SAMPLE_CENTER)
+            dgs.close()
+        finally:
+            ctx.set_option("strip_px", 256)
+        assert inst in desc and ("cov4_kernel<4" not in desc), (px, desc)
+        assert np.array_equal(got, ref), px
