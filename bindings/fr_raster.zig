@@ -88,6 +88,7 @@ pub extern "c" fn fr_font_open(ttf_bytes: *const anyopaque, len: usize, flags: u
 pub extern "c" fn fr_font_close(font: ?*fr_font) void;
 pub extern "c" fn fr_font_info(font: *const fr_font, units_per_em: ?*u16, num_glyphs: ?*u16, y0_baseline: ?*c_int) c_int;
 pub extern "c" fn fr_font_char_to_glyph(font: *const fr_font, codepoint: u32, glyph_index: *u16) c_int;
+pub extern "c" fn fr_font_glyph_advance(font: *const fr_font, glyph_index: u16, advance_width: *i16) c_int;
 pub extern "c" fn fr_font_glyph_measure(font: *fr_font, glyph_index: u16, n_contours: *u32, n_points: *u32, box: *[4]i16) c_int;
 pub extern "c" fn fr_font_glyph_fill(font: *fr_font, glyph_index: u16, points_xy: [*]i16, contour_start: [*]u32) c_int;
 // ---- QOI writer (host side; byte-compatible with tools/qoi.zig, which the Zig host keeps)

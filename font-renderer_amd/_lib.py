@@ -75,6 +75,7 @@ SYMBOLS = [
     ("fr_font_close", None, [_P]),
     ("fr_font_info", C.c_int, [_P, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int)]),
     ("fr_font_char_to_glyph", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint16)]),
+    ("fr_font_glyph_advance", C.c_int, [_P, C.c_uint16, C.POINTER(C.c_int16)]),
     ("fr_font_glyph_measure", C.c_int, [_P, C.c_uint16, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
     ("fr_font_glyph_fill", C.c_int, [_P, C.c_uint16, _P, _P]),
     ("fr_qoi_bound", C.c_size_t, [C.c_uint32, C.c_uint32]),

@@ -321,6 +321,7 @@ static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t cou
 {
     p->parts.clear();
     p->fast_ns = ns;
+    if (ns <= 0) return;                                              // (no fast kernel in this plan)
     const uint32_t prb = ns == 1 ? 16u : 64u / (uint32_t)ns;          // pixel rows of a band
     uint32_t first = 0;
     for (int c = 0; c < 9; ++c) {

@@ -42,7 +42,8 @@ struct fr_font {
     std::vector<uint8_t> d;
     uint16_t units_per_em = 0, num_glyphs = 0;
     bool y0_baseline = false, loca_long = false, allow_hinted = false;
-    size_t pos_loca = 0, pos_glyf = 0, pos_cmap_sub = 0;
+    size_t pos_loca = 0, pos_glyf = 0, pos_cmap_sub = 0, pos_hmtx = 0;
+    uint16_t num_long_hor_metrics = 0;
     int cmap_format = 0;
     std::vector<GlyphData> glyphs;
     size_t composite_depth = 0;     // load_composite frames currently on the stack
@@ -334,7 +335,7 @@ int fr_font_open(const void *data, size_t len, uint32_t flags, fr_font **out)
     if (!f->has(0, 12)) return bail(set_error(FR_E_INVALID, "not a TrueType file"));
     const uint16_t n_tables = f->u16(4);                                             // OffsetSubtable, Font.zig:38
     if (!f->has(12, 16u * n_tables)) return bail(set_error(FR_E_INVALID, "truncated table directory"));
-    size_t head = 0, maxp = 0, cmap = 0, loca = 0, glyf = 0;
+    size_t head = 0, maxp = 0, cmap = 0, loca = 0, glyf = 0, hhea = 0, hmtx = 0;
     for (uint16_t t = 0; t < n_tables; ++t) {
         const size_t e = 12 + 16u * t;
         const uint32_t tg = f->u32(e), off = f->u32(e + 8);
@@ -343,6 +344,8 @@ int fr_font_open(const void *data, size_t len, uint32_t flags, fr_font **out)
         else if (tg == tag("cmap")) cmap = off;
         else if (tg == tag("loca")) loca = off;
         else if (tg == tag("glyf")) glyf = off;
+        else if (tg == tag("hhea")) hhea = off;
+        else if (tg == tag("hmtx")) hmtx = off;
     }
     if (!head || !maxp || !cmap || !loca || !glyf) return bail(set_error(FR_E_INVALID, "missing head/maxp/cmap/loca/glyf table"));   // Font.zig:43-59
     if (!f->has(head, 54) || !f->has(maxp, 6)) return bail(set_error(FR_E_INVALID, "truncated head/maxp"));
@@ -351,6 +354,11 @@ int fr_font_open(const void *data, size_t len, uint32_t flags, fr_font **out)
     f->loca_long = f->i16(head + 50) != 0;
     f->num_glyphs = f->u16(maxp + 4);
     f->pos_loca = loca; f->pos_glyf = glyf;
+    // hhea / hmtx: Font.zig:64-69 (both required there too)
+    if (!hhea || !hmtx) return bail(set_error(FR_E_INVALID, "missing hhea/hmtx table"));
+    if (!f->has(hhea, 36)) return bail(set_error(FR_E_INVALID, "truncated hhea"));
+    f->num_long_hor_metrics = f->u16(hhea + 34);
+    f->pos_hmtx = hmtx;
     f->glyphs.resize(f->num_glyphs);
     // cmap: Font.zig:87-121
     if (!f->has(cmap, 4)) return bail(set_error(FR_E_INVALID, "truncated cmap"));
@@ -382,6 +390,22 @@ int fr_font_info(const fr_font *font, uint16_t *units_per_em, uint16_t *num_glyp
     if (units_per_em) *units_per_em = font->units_per_em;
     if (num_glyphs) *num_glyphs = font->num_glyphs;
     if (y0_baseline) *y0_baseline = font->y0_baseline ? 1 : 0;
+    return FR_OK;
+}
+
+// Font.getGlyph's second result (Font.zig:161-169): advance_widths[glyph_index] as loadAdvanceWidths fills it
+// (Font.zig:123-139) — for the first num_of_long_hor_metrics glyphs the advance of their LongHorMetric read as i16
+// (:129), for the others the i16 entries that follow the long metrics (:132).  (Those trailing entries are the
+// left-side bearings in the TrueType layout; the reference hands them out as advances — kept as it is, cited.)
+int fr_font_glyph_advance(const fr_font *font, uint16_t glyph_index, int16_t *advance_width)
+{
+    if (!font || !advance_width) return set_error(FR_E_INVALID, "fr_font_glyph_advance: NULL argument");
+    const fr_font &f = *font;
+    if (glyph_index >= f.num_glyphs) return set_error(FR_E_INVALID, "glyph index %u of %u", (unsigned)glyph_index, (unsigned)f.num_glyphs);
+    const size_t n_long = f.num_long_hor_metrics;
+    const size_t at = glyph_index < n_long ? f.pos_hmtx + 4u * glyph_index : f.pos_hmtx + 4u * n_long + 2u * (glyph_index - n_long);
+    if (!f.has(at, 2)) return set_error(FR_E_INVALID, "truncated hmtx");
+    *advance_width = f.i16(at);
     return FR_OK;
 }
 

@@ -1,7 +1,7 @@
 """Font — host-side mirror of /root/reference/src/font/Font.zig on the C ABI's contour producer
 (fr_font_*: TrueType glyf/loca walk restated in C++, font-renderer_amd/csrc/fr_font.cpp).
 Same surface as the reference: Font.initTTF(file) (:31), font.information (:25-29),
-font.getGlyph(char) -> (Glyph, advance is not reproduced) (:161), plus glyph-index access and a
+font.getGlyph(char) -> (Glyph, advance_width) (:161-169), plus glyph-index access and a
 whole-font GlyphSet for batch rendering."""
 from __future__ import annotations
 
@@ -48,8 +48,14 @@ class Font:
         contours = [Contour(pts[int(cs[c]):int(cs[c + 1])].copy()) for c in range(nc.value)]
         return Glyph(Box(int(box[0]), int(box[1]), int(box[2]), int(box[3])), contours)
 
-    def getGlyph(self, char: int) -> Glyph:                            # Font.zig:161
-        return self.glyph_by_index(self.glyph_index(char))
+    def advance_width(self, gi: int) -> int:                           # Font.advance_widths[gi] (Font.zig:123-139)
+        a = C.c_int16()
+        L.check(self._lib.fr_font_glyph_advance(self._h, gi, C.byref(a)))
+        return a.value
+
+    def getGlyph(self, char: int):                                     # Font.zig:161-169 -> struct {Glyph, i16}
+        gi = self.glyph_index(char)
+        return self.glyph_by_index(gi), self.advance_width(gi)
 
     def glyphset(self, glyph_indices: Optional[Iterable[int]] = None, skip_unsupported: bool = True):
         """-> (GlyphSet, kept glyph indices): the whole font (or the given indices) ready for

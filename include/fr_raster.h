@@ -261,6 +261,8 @@ int fr_font_open(const void *ttf_bytes, size_t len, uint32_t flags, fr_font **ou
 void fr_font_close(fr_font *font);
 int fr_font_info(const fr_font *font, uint16_t *units_per_em, uint16_t *num_glyphs, int *y0_baseline);
 int fr_font_char_to_glyph(const fr_font *font, uint32_t codepoint, uint16_t *glyph_index);
+/* Font.getGlyph's advance_width (Font.zig:161-169, hmtx read as Font.zig:123-139 reads it), font units */
+int fr_font_glyph_advance(const fr_font *font, uint16_t glyph_index, int16_t *advance_width);
 int fr_font_glyph_measure(fr_font *font, uint16_t glyph_index, uint32_t *n_contours, uint32_t *n_points, int16_t box[4]);
 int fr_font_glyph_fill(fr_font *font, uint16_t glyph_index, int16_t *points_xy, uint32_t *contour_start);
 

@@ -11,7 +11,7 @@ import font_renderer_amd as fr
 import oracle_lib as O
 from font_renderer_amd import render_glyph as rg
 from font_renderer_amd.atlas import atlas_shape, cell_jobs, glyph_dims_jobs
-from font_renderer_amd.glyph import GlyphSet
+from font_renderer_amd.glyph import Box, Contour, Glyph, GlyphSet
 from font_renderer_amd.synth import comb_glyph, stroke_glyphset, synth_glyphset
 
 pytestmark = pytest.mark.gpu
@@ -108,7 +108,10 @@ def test_two_by_two_samples_on_cov4(ctx, oracle, segs, cell):
 def test_two_by_two_overfull_rows_and_tall_cells(ctx, oracle):
     """n = 2: combs whose rays meet 80 / 12 crossings with 8 / 16 / 32 kept per sample row (the direct sum inside
     cov4_kernel<.., 2>), and a 200 x 1000 cell (2000 sample rows: the 12-bit row fields' limit is 2048)"""
-    gl = [comb_glyph(40), comb_glyph(6)]
+    gl = []
+    for teeth in (40, 6):
+        cs, box = comb_glyph(teeth)
+        gl.append(Glyph(Box(*[int(v) for v in box]), [Contour(c) for c in cs]))
     gs = GlyphSet(gl)
     jobs = cell_jobs(gs, 160, 150, 2048, 2)
     ref = np.full((160, 320), 0x5b, np.uint8)
