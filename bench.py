@@ -35,6 +35,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: 95 glyphs, 128x128 cells, one 2048^2 atlas
     "c2_ascii95_128px_s32_16spp": dict(glyphs=95, cell=128, segs=32, n=4, cols=16),
     "c2_ascii95_real_128px_16spp": dict(glyphs=95, cell=128, segs=0, n=4, cols=16, gen="ascii"),
+    # configs[1] without the launch bound: 64 such pages (64 x 95 different glyphs, each page its own 2048^2) stacked in one
+    # buffer and rendered by ONE plan = one launch per step
+    "c2_ascii95_128px_s32_16spp_x64pages": dict(glyphs=95 * 64, cell=128, segs=32, n=4, cols=16, gen="pages", per_page=95, page_rows=16),
     # BASELINE.json configs[3] per-GPU share (BMP/8 = 7936 glyphs, 128^2, 16 samples)
     "c4_bmp_shard_128px_s32_16spp": dict(glyphs=7936, cell=128, segs=32, n=4, cols=64),
     # BASELINE.json configs[4] per-GPU share (4 096 glyphs / 8 = 512, 512^2 cells): build-defined SDF, 1 sample
@@ -54,6 +57,8 @@ WORKLOADS = {
     "c3_cjk21k_256px_s128_winding_i16": dict(glyphs=20992, cell=256, segs=128, n=1, cols=64, mode="winding_i16"),
     # the reference's own product on the real font: renderGlyph's gray map of every DejaVuSerif-Italic glyph, 6 sizes
     "real_dejavuserif_italic_whole_font_256px_gray_debug": dict(glyphs=0, cell=256, segs=0, n=1, cols=64, gen="font", font=DEJAVU, mode="gray_debug"),
+    # BASELINE.json configs[4] as stated: per-pixel SDF at 512 x 512 per glyph, the WHOLE font (every loadable glyph once)
+    "real_dejavuserif_italic_whole_font_512px_sdf": dict(glyphs=0, cell=512, segs=0, n=1, cols=16, gen="font", font=DEJAVU, mode="sdf", size_factors=(1.0,)),
     # the reference's literal product in batch (render_glyph.zig:11-33): every glyph of the font at EXACTLY renderGlyph's own
     # image size for font_size 64 (47 x 45-ish images), shelf-packed tight into one atlas — ragged cells on the fast kernels
     "real_dejavuserif_italic_renderglyph_dims_size64_gray_debug": dict(glyphs=0, cell=0, segs=0, n=1, cols=0, gen="font_dims", font=DEJAVU, mode="gray_debug", sizes=(64,), atlas_w=4096),
@@ -87,7 +92,7 @@ def build_inputs(wl, rank, lo, hi):
         font = fr.Font.initTTF(wl["font"])
         gs, kept = font.glyphset()
         upm = font.information.units_per_em
-        sizes = [int(cell * f) for f in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5)]
+        sizes = [int(cell * f) for f in wl.get("size_factors", (1.0, 0.9, 0.8, 0.7, 0.6, 0.5))]
         jobs = np.concatenate([cell_jobs(gs, cell, s, upm, cols) for s in sizes])
         k = np.arange(len(jobs))
         jobs["out_x"] = (k % cols) * cell
@@ -100,6 +105,17 @@ def build_inputs(wl, rank, lo, hi):
         return asc.gs, jobs, atlas_shape(95, cell, cols)
     make = stroke_glyphset if gen == "stroke" else synth_glyphset
     gs = make(hi - lo, wl["segs"], first_index=lo)
+    if gen == "pages":
+        # pages of `per_page` glyphs on a cols x page_rows cell grid, stacked one under the other in ONE buffer
+        per, pr = wl["per_page"], wl["page_rows"]
+        n_pages = (hi - lo + per - 1) // per
+        parts = []
+        for pg in range(n_pages):
+            a, b = pg * per, min((pg + 1) * per, hi - lo)
+            jb = cell_jobs(gs, cell, cell, 2048, cols, first_glyph=a, n_glyphs=b - a)
+            jb["out_y"] += pg * pr * cell
+            parts.append(jb)
+        return gs, np.concatenate(parts), (n_pages * pr * cell, cols * cell)
     return gs, cell_jobs(gs, cell, cell, 2048, cols), atlas_shape(hi - lo, cell, cols)
 
 

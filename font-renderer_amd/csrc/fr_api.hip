@@ -107,6 +107,8 @@ struct fr_plan {
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
     uint32_t *d_job_seg = nullptr;     // [n_jobs][2]: first segment and segment count of the job's glyph
+    uint32_t *d_bits = nullptr;        // FR_SDF_U8: the sign bit planes of the fast kernels' jobs (one bit per pixel, rows of
+    uint32_t *d_job_bits = nullptr;    // ceil(w / 32) words) and each job's first word in them (0xffffffff: a general-kernel job)
     uint32_t *d_large = nullptr;       // distinct glyphs of more than 128 segments among the jobs: their records are
     uint32_t n_large = 0;              // rebuilt by prepare_kernel before every render (the others: inside the render kernel)
     uint32_t n_jobs = 0;
@@ -474,7 +476,7 @@ void fr_plan_destroy(fr_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    dfree(plan->d_jobs); dfree(plan->d_job_seg); dfree(plan->d_large);
+    dfree(plan->d_jobs); dfree(plan->d_job_seg); dfree(plan->d_large); dfree(plan->d_bits); dfree(plan->d_job_bits);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
     delete plan;
@@ -592,6 +594,21 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     if (e == hipSuccess && n_jobs) e = hipMalloc(&p->d_job_seg, (size_t)n_jobs * 8);
     if (e == hipSuccess && n_jobs)
         e = hipMemcpyAsync(p->d_job_seg, jseg.data(), (size_t)n_jobs * 8, hipMemcpyHostToDevice, ctx->stream);
+    // FR_SDF_U8: the sign of a fast job travels as one bit per pixel in a plane of its own (win1_kernel's sign-bit mode
+    // writes it, sdf_kernel reads it and is then the only writer of the output)
+    std::vector<uint32_t> jbits;
+    if (params->mode == FR_SDF_U8 && n_fast) {
+        jbits.assign(n_jobs, 0xffffffffu);
+        uint64_t words = 0;
+        for (uint32_t q = 0; q < n_fast; ++q) {
+            jbits[q] = (uint32_t)words;
+            words += (uint64_t)((sorted_jobs[q].w + 31u) / 32u) * sorted_jobs[q].h;
+            if (words >= 0xffffffffull) { e = hipErrorInvalidValue; break; }
+        }
+        if (e == hipSuccess) e = hipMalloc(&p->d_bits, (size_t)(words ? words : 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(&p->d_job_bits, (size_t)n_jobs * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_job_bits, jbits.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
@@ -631,7 +648,7 @@ int fr_plan_describe(const fr_plan *plan, char *buf, size_t cap)
         a.strip_w = 16u << pt.wlog;
         name[0] = 0;
         if (plan->fast_ns > 1) (void)fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, nullptr, false, name, sizeof name);
-        else (void)fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, nullptr, false, name, sizeof name);
+        else (void)fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : (pm == FR_SDF_U8 ? 3 : 2)), pt.rec_cap, nullptr, false, name, sizeof name);
         add(name, pt.cnt);
     }
     if (plan->n_jobs > plan->n_fast) {
@@ -663,6 +680,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     a.pts = plan->gs->d_pts;
     a.seg_p0 = plan->gs->d_seg_p0;
     a.seg_pts = plan->gs->d_seg_pts;
+    a.job_bits = nullptr; a.bits = nullptr;
     // fused: the render kernel builds the records of every glyph of <= 128 segments (<= 256 candidate roots)
     // in LDS itself — decided per job inside the kernel; larger glyphs are staged from HBM
     a.fused = plan->ctx->fuse_prepare ? 1u : 0u;
@@ -735,6 +753,14 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         const int pm = plan->params.mode;
         hipStream_t pst = (forked && i != big) ? ctx->aux : ctx->stream;
         if (plan->fast_ns > 1) HIP_TRY(fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, pst));
+        else if (sdf && plan->d_bits) {
+            // the sign pass of FR_SDF_U8: one bit per pixel into the job's own bit plane
+            void *const keep = a.out;
+            a.out = plan->d_bits; a.job_bits = plan->d_job_bits + pt.first;
+            const hipError_t le = fr::launch_win1(a, 3, pt.rec_cap, pst);
+            a.out = keep; a.job_bits = nullptr;
+            HIP_TRY(le);
+        }
         else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, pst));
     }
     return FR_OK;
@@ -747,6 +773,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     if (rc_parts) return rc_parts;
     if (sdf) {
         a.strip_w = plan->strip_w;
+        a.bits = plan->d_bits; a.job_bits = plan->d_job_bits;
         a.jobs = plan->d_jobs;
         a.job_seg = plan->d_job_seg;
         a.n_jobs = plan->n_jobs;
@@ -937,7 +964,7 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
         std::vector<std::pair<int32_t, int32_t>> ev;
         const int cls = fast_class(rule, w, h, ns, glyph_root_bound(points_xy, seg_p0.data(), 0, ns),
                                    glyph_ray_bound(points_xy, seg_p0.data(), 0, ns, ev));
-        if (cls) {
+        if (cls && mode != FR_SDF_U8) {            // (one SDF image: the sign comes as a byte from the general kernel, no bit plane)
             uint32_t counts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             counts[cls - 1] = 1;
             pl.n_fast = 1;

@@ -90,6 +90,9 @@ struct RenderArgs {
     const uint32_t *seg_p0;            // glyph's records itself (in LDS) when `fused` is set
     const int16_t *seg_pts;            // the same control points laid out per segment (6 x i16 each): cov4_kernel reads
                                        // its segment with one load instead of two dependent ones
+    const uint32_t *job_bits;          // win1_kernel's sign-bit mode / sdf_kernel: first word of each job's bit plane, or
+                                       // 0xffffffff for a job whose sign is the byte the general kernel left in the output
+    const uint32_t *bits;              // sdf_kernel: the bit planes (win1_kernel's sign-bit mode writes them through `out`)
     uint32_t fused;
     uint32_t uniform;                  // every job: w a multiple of strip_w, h a multiple of the wave band (64/n rows)
     void *out;

@@ -9,8 +9,10 @@
 //                t in [0,1], of |B(t) - q| (font units): 9 uniform probes, then 4 Newton steps on
 //                (B(t)-q).B'(t) = 0 clamped to the probe's neighbourhood; times `scale` -> pixels
 //   sign       : + inside (winding != 0, the reference's non-zero test on its own winding number,
-//                render_glyph.zig:29,35-73), - outside; taken from the byte render_kernel's 1-sample
-//                coverage left in the output (255 / 0) right before this kernel
+//                render_glyph.zig:29,35-73), - outside; one BIT per pixel in a job-local bit plane that
+//                win1_kernel's sign-bit mode wrote right before this kernel (an eighth of the bytes of a mask, and
+//                every output byte is then written exactly once, by this kernel) — or, for the few jobs only the
+//                general render_kernel takes, the byte (255 / 0) its 1-sample coverage left in the output
 //   encoding   : u8 = clamp(floor(128 + 16*d + 0.5), 0, 255)   (8 pixels of range either side)
 //
 // Shape: one WAVE (a 64-lane workgroup, no barriers) per 32x32-pixel region of a cell, taken as 16 quads of
@@ -25,8 +27,8 @@
 //            holds what does not depend on the sample: A, the second difference and the probe points B(k/8);
 //   quad   : the list's entries against the 16 quads' sample boxes (4 entries x 16 quads per step, each box projected
 //            onto the segment's frame); the ballots are the quads' candidate sets.
-//            A quad without candidates keeps the byte the sign pass left (255 / 0 — what the encoding gives
-//            for "farther than 8 pixels"), so nothing is read or written for it;
+//            A quad without candidates is "farther than 8 pixels": its bytes are the saturated encoding, 255 / 0
+//            by the sign bit (a whole region without candidates: one 16-byte store per lane);
 //   pixel  : per candidate, the pixel's own box distance against the reach and against the best so far.
 // The distance the kernel computes is the distance to SOME point of the curve, hence >= the box distance: every
 // skipped segment would have produced a value past the clamp or not below the minimum, so the minimum over the
@@ -133,11 +135,13 @@ template <bool MULTI>
 __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ job_seg,
                                                  const int16_t *__restrict__ seg_pts, uint8_t *__restrict__ out,
                                                  uint64_t out_stride, uint32_t regions_x, uint32_t regions_y,
-                                                 int phase_center, int cull)
+                                                 int phase_center, int cull, const uint32_t *__restrict__ bits,
+                                                 const uint32_t *__restrict__ job_bits)
 {
     __shared__ __attribute__((aligned(16))) float s_seg[SDF_BLOCK * SDF_ENTRY];
     __shared__ float s_best[MULTI ? 16u * 64u : 1u];     // per-pixel minima of the region between blocks of segments
     __shared__ float s_xy[64];                  // the region's 32 sample abscissae, then its 32 sample ordinates
+    __shared__ uint32_t s_bits[32];             // the sign bits of the region's 32 rows (bit x of word y: pixel (X0 + x, Y0 + y))
     uint32_t bid = blockIdx.x;
     const uint32_t rxi = bid % regions_x; bid /= regions_x;
     const uint32_t ryi = bid % regions_y;
@@ -153,6 +157,13 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     const float xy = lane < 32u ? ((float)(job.min_x + (int32_t)(X0 + lane)) + off) / scale
                                 : ((float)(job.max_y - (int32_t)(Y0 + lane - 32u)) - off) / scale;
     s_xy[lane] = xy;
+    // the sign: one word of the job's bit plane per region row (the plane's rows are ceil(w / 32) words; X0 is a
+    // multiple of 32) — or, for a job of the general kernel, the byte that kernel left in the output
+    const uint32_t jb = job_bits ? job_bits[jidx] : 0xffffffffu;
+    const bool use_bits = jb != 0xffffffffu;                    // (wave-uniform)
+    if (use_bits && lane < 32u)
+        s_bits[lane] = (Y0 + lane < job.h) ? bits[(size_t)jb + (size_t)(Y0 + lane) * ((job.w + 31u) / 32u) + X0 / 32u] : 0u;
+    uint32_t done = 0u;                          // quads whose bytes are final (wave-uniform, one bit per quad)
     // A set of sample points is tested as the disc about its box's centre: radius = half the diagonal, plus the
     // pixel test's slack at its farthest corner (see there), plus a margin for the roundings of this very sum.
     // Both maps are monotone in the pixel index, so the corners are the first and last column / row.
@@ -291,9 +302,11 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
                 touched |= 1u << q;
                 continue;
             }
+            done |= 1u << q;
             if (!valid) continue;
             uint8_t *px = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
-            const bool inside = *px != 0;          // the sign pass: winding != 0 at this sample
+            // the sign pass: winding != 0 at this sample
+            const bool inside = use_bits ? ((s_bits[(q >> 2) * 8u + (lane >> 3)] >> ((q & 3u) * 8u + (lane & 7u))) & 1u) != 0u : *px != 0;
             float d = __builtin_sqrtf(best) * scale;
             if (!inside) d = -d;
             float v = 16.0f * d + 128.0f;
@@ -301,6 +314,38 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
             v = fminf(fmaxf(v, 0.0f), 255.0f);
             *px = (uint8_t)v;
         }
+    }
+    if (!use_bits) return;                       // (the sign bytes already ARE the saturated encoding of every other quad)
+    // ---- everything farther than the reach from the outline: the saturated encoding, 255 inside / 0 outside
+    __syncthreads();                             // (one wave; s_bits is written)
+    if (done == 0u) {
+        // the whole region: lane = 16 pixels of one row (row lane >> 1, half lane & 1), one 16-byte store
+        const uint32_t row = lane >> 1, x0 = X0 + 16u * (lane & 1u), y = Y0 + row;
+        if (y < job.h && x0 < job.w) {
+            const uint32_t b16 = (s_bits[row] >> (16u * (lane & 1u))) & 0xffffu;
+            // four sign bits -> four bytes 0 / 255: 1 + 2^7 + 2^14 + 2^21 puts bit i at bit 8 i
+            auto spread = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 255u; };
+            const uint32_t w4[4] = {spread(b16), spread(b16 >> 4), spread(b16 >> 8), spread(b16 >> 12)};
+            uint8_t *dst = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x0;
+            if (x0 + 16u <= job.w) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef u32x4 u32x4_u __attribute__((aligned(1)));
+                const u32x4 v = {w4[0], w4[1], w4[2], w4[3]};
+                *reinterpret_cast<u32x4_u *>(dst) = v;
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i)
+                    if (x0 + i < job.w) dst[i] = (uint8_t)(w4[i >> 2] >> (8u * (i & 3u)));
+            }
+        }
+        return;
+    }
+    for (uint32_t q = 0; q < 16u; ++q) {
+        if ((done >> q) & 1u) continue;
+        const uint32_t x = X0 + (q & 3u) * 8u + (lane & 7u), y = Y0 + (q >> 2) * 8u + (lane >> 3);
+        if (x < job.w && y < job.h)
+            out[((size_t)job.out_y + y) * out_stride + job.out_x + x] =
+                ((s_bits[(q >> 2) * 8u + (lane >> 3)] >> ((q & 3u) * 8u + (lane & 7u))) & 1u) ? 255u : 0u;
     }
 }
 
@@ -312,10 +357,10 @@ hipError_t launch_sdf(const RenderArgs &a, uint32_t max_w, uint32_t max_h, uint3
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     if (max_seg > SDF_BLOCK)
         hipLaunchKernelGGL(sdf_kernel<true>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
-                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
+                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull, a.bits, a.job_bits);
     else
         hipLaunchKernelGGL(sdf_kernel<false>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
-                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull);
+                           reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull, a.bits, a.job_bits);
     return hipGetLastError();
 }
 

@@ -18,7 +18,10 @@
 
 namespace fr {
 
-enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2 };
+// MODE1_BITS: the non-zero mask as ONE BIT per pixel in a job-local bit plane (A.out = the plane's base, A.job_bits[j] =
+// the job's first 32-bit word, rows of ceil(w / 32) words, bit x % 32 of word x / 32 = pixel x) — the sign the SDF
+// kernel reads (fr_sdf.hip): an eighth of the bytes of the mask, and the output itself is then written only once
+enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2, MODE1_BITS = 3 };
 enum { W1_ROWS = 16 };
 
 template <int WLOG, int RPL>
@@ -236,9 +239,14 @@ void win1_kernel(const RenderArgs A)
         }
         c4_wave_lds_sync();
         const uint32_t cnt = s_cnt[lane & 15u] & 0xffffu;
-        unsigned char *const out_band = reinterpret_cast<unsigned char *>(A.out) +
-                                        (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
-        const size_t row_bytes = (size_t)A.out_stride * ESZ;
+        // (bit plane: rows of ceil(w / 32) words from the job's first word; a strip starts on a 64-bit boundary)
+        const size_t row_bytes = (MODE == MODE1_BITS) ? (size_t)((job.w + 31u) / 32u) * 4u : (size_t)A.out_stride * ESZ;
+        unsigned char *const out_band = (MODE == MODE1_BITS)
+            ? reinterpret_cast<unsigned char *>(A.out) + (size_t)A.job_bits[jidx] * 4u + (size_t)y0 * row_bytes + x0s / 8u
+            : reinterpret_cast<unsigned char *>(A.out) + (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
+        // 16 sign bits of window wx go to bytes 2 wx, 2 wx + 1 of the strip's part of the row — unless the window lies
+        // past the row's last word
+        const bool bits_ok = 16u * wx + x0s < ((job.w + 31u) & ~31u);
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
@@ -248,6 +256,10 @@ void win1_kernel(const RenderArgs A)
             const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
             const uint4 v = make_uint4(bg, bg, bg, bg);
             for (uint32_t yl = lane >> WLOG; yl < W1_ROWS; yl += (64u >> WLOG)) {
+                if (MODE == MODE1_BITS) {
+                    if (yl < hlim && bits_ok) *reinterpret_cast<uint16_t *>(out_band + (size_t)yl * row_bytes + 2u * wx) = 0;
+                    continue;
+                }
                 unsigned char *dst = out_band + (size_t)yl * row_bytes + 16u * ESZ * wx;
                 if (edge) w1_store_clip<ESZ>(dst, v, v, yl < hlim ? (int)wlim - (int)(16u * wx) : 0);
                 else if (ESZ == 2u) { __builtin_memcpy(dst, &v, 16); __builtin_memcpy(dst + 16, &v, 16); }
@@ -306,7 +318,14 @@ void win1_kernel(const RenderArgs A)
                 }
                 const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
                 const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);
-                if (16u * lane < wlim && r < hlim) {
+                if (MODE == MODE1_BITS) {
+                    if (16u * lane < NCOL && r < hlim && 16u * lane + x0s < ((job.w + 31u) & ~31u)) {
+                        uint32_t bits16 = 0;
+#pragma unroll
+                        for (int cc = 0; cc < 16; ++cc) bits16 |= (wl[cc] + right != 0 ? 1u : 0u) << cc;
+                        *reinterpret_cast<uint16_t *>(out_band + (size_t)r * row_bytes + 2u * lane) = (uint16_t)bits16;
+                    }
+                } else if (16u * lane < wlim && r < hlim) {
                     unsigned char *dst = out_band + (size_t)r * row_bytes + 16u * ESZ * lane;
                     const int mlim = (int)wlim - (int)(16u * lane);
 #pragma unroll
@@ -354,7 +373,17 @@ void win1_kernel(const RenderArgs A)
             if ((ovf_rows >> prow) & 1u) continue;                          // stored by the direct path above
             unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
             const int mclip = prow < hlim ? (int)wlim - (int)(16u * wx) : 0;   // (edge only) pixels of my window inside the cell
-            if (MODE == MODE1_MASK) {
+            if (MODE == MODE1_BITS) {
+                // bit 7 of every byte <- (w != 0), then the four bits of a dword gathered by one multiply
+                // (2^24 + 2^17 + 2^10 + 2^3 puts bits 0, 8, 16, 24 at 24 .. 27; no two partial products meet)
+                auto b4 = [](uint32_t x) -> uint32_t {
+                    const uint32_t z = x ^ 0x60606060u;
+                    const uint32_t nz = (((z + 0x7f7f7f7fu) | z) & 0x80808080u) >> 7;
+                    return (nz * 0x01020408u) >> 24;
+                };
+                const uint32_t bits16 = (b4(p0) & 15u) | ((b4(p1) & 15u) << 4) | ((b4(p2) & 15u) << 8) | ((b4(p3) & 15u) << 12);
+                if (prow < hlim && bits_ok) *reinterpret_cast<uint16_t *>(out_band + (size_t)prow * row_bytes + 2u * wx) = (uint16_t)bits16;
+            } else if (MODE == MODE1_MASK) {
                 auto m4 = [](uint32_t x) -> uint32_t {
                     const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
                     const uint32_t nz = ((z + 0x7f7f7f7fu) | z) & 0x80808080u;
@@ -424,6 +453,7 @@ static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hip
     };
     if (mode == MODE1_WINDING_I16) return launch(win1_kernel<WLOG, MODE1_WINDING_I16, RPL>);
     if (mode == MODE1_GRAY_DEBUG) return launch(win1_kernel<WLOG, MODE1_GRAY_DEBUG, RPL>);
+    if (mode == MODE1_BITS) return launch(win1_kernel<WLOG, MODE1_BITS, RPL>);
     return launch(win1_kernel<WLOG, MODE1_MASK, RPL>);
 }
 
@@ -437,7 +467,7 @@ static hipError_t win1_launch_rpl(const RenderArgs &a, int mode, uint32_t rec_ca
 
 // jobs: cells of any size up to 2048 rows (strips of a.strip_w in {64, 128, 256} pixels and bands of 16 rows; the last of
 // each may be partial), one sample per pixel, glyphs with <= 384 segments and <= rec_cap possible root records.
-// mode: 0 winding_i16, 1 gray_debug, 2 mask.  launch = false: only name the instance (as rocprofv3 prints it).
+// mode: 0 winding_i16, 1 gray_debug, 2 mask, 3 sign bits (one per pixel, job-local bit plane).  launch = false: only name the instance (as rocprofv3 prints it).
 hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream, bool launch, char *name, size_t name_cap)
 {
     const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);

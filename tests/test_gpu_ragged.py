@@ -157,3 +157,87 @@ def test_strip_px_option_bounds_the_fast_strips(ctx, oracle, ascii_set):
             ctx.set_option("strip_px", 256)
         assert inst in desc and ("cov4_kernel<4" not in desc), (px, desc)
         assert np.array_equal(got, ref), px
+
+
+def test_sdf_on_ragged_cells_and_mixed_plans(ctx, oracle, ascii_set):
+    """FR_SDF_U8 with the sign travelling as one bit per pixel (win1_kernel's sign-bit mode -> sdf_kernel, which is then the
+    only writer of the output): renderGlyph-sized images (ragged, unaligned) of real glyphs, and a plan that mixes fast
+    jobs (bit planes) with a 520-segment glyph (general kernel: the sign as a byte in the output), against the CPU twin;
+    the bytes around every cell stay untouched"""
+    gs = ascii_set.gs
+    jobs, H = glyph_dims_jobs(gs, 90, ascii_set.g_upm, 1531, n_glyphs=120)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    for center in (False, True):
+        got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_SDF_U8, O.SDF_U8, (H + 2, 1531), 1, center, dgs, 0,
+                               ["fr::win1_kernel<", ", 3, ", "fr::sdf_kernel"])
+        assert np.array_equal(got, ref), (center, desc)
+    dgs.close()
+    parts = [synth_glyphset(3, 40, first_index=21), synth_glyphset(1, 520, first_index=22), synth_glyphset(2, 100, first_index=23)]
+    gs = GlyphSet([p.glyph(i) for p in parts for i in range(len(p))])
+    jobs = cell_jobs(gs, 200, 180, 2048, 3)
+    jobs["w"] = [200, 131, 64, 200, 33, 190]
+    jobs["h"] = [200, 77, 200, 150, 31, 200]
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_SDF_U8, O.SDF_U8, atlas_shape(len(gs), 200, 3), 1, True, dgs, 1, ["render_kernel", "win1_kernel"])
+    dgs.close()
+    assert np.array_equal(got, ref), desc
+
+
+def test_full_size_properties_config5_shard_of_the_real_font(ctx, oracle):
+    """BASELINE configs[4] as stated — per-pixel SDF at 512 x 512 per glyph, whole font — at one GPU's share of
+    DejaVuSerif-Italic through the C-side producer (the first 384 loadable glyphs): deterministic (two renders equal),
+    8 sub-shards == unsharded, culls on == culls off, four cells == the CPU twin."""
+    import os
+    import torch
+    path = "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"
+    if not os.path.exists(path):
+        pytest.skip("DejaVuSerif-Italic.ttf not in this image")
+    font = fr.Font.initTTF(path)
+    gs_all, kept = font.glyphset()
+    G, cell, cols = 384, 512, 16
+    gs = gs_all.subset(0, G)
+    upm = font.information.units_per_em
+    jobs = cell_jobs(gs, cell, cell, upm, cols)
+    H, W = atlas_shape(G, cell, cols)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    plan = fr.Plan(dgs, jobs, fr.FR_SDF_U8, 1, fr.FR_SAMPLE_CENTER)
+    assert plan.pixels == G * cell * cell and plan.stats()["jobs_general"] == 0, plan.describe()
+    first = torch.full((H, W), 0x5b, dtype=torch.uint8, device="cuda")
+    again = torch.full((H, W), 0xa4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan.render(first.data_ptr(), W, H); plan.render(again.data_ptr(), W, H); ctx.sync()
+    assert torch.equal(first, again)                                    # every byte written, the same both times
+    plan.close()
+    # 8 sub-shards (the 8 GPUs of configs[4]) into the unsharded atlas
+    from font_renderer_amd.shard import shard_ranges
+    out2 = torch.zeros_like(first)
+    for lo, hi in shard_ranges(G, 8):
+        sub = gs.subset(lo, hi)
+        sd = fr.DeviceGlyphSet(ctx, sub)
+        sj = cell_jobs(sub, cell, cell, upm, cols).copy()
+        sj["out_x"] = ((np.arange(lo, hi) % cols) * cell).astype(np.uint32)
+        sj["out_y"] = ((np.arange(lo, hi) // cols) * cell).astype(np.uint32)
+        sp = fr.Plan(sd, sj, fr.FR_SDF_U8, 1, fr.FR_SAMPLE_CENTER)
+        sp.render(out2.data_ptr(), W, H); ctx.sync()
+        sp.close(); sd.close()
+    assert torch.equal(out2, first)
+    try:
+        ctx.set_option("sdf_cull", 0)
+        few = jobs[:32]
+        p2 = fr.Plan(dgs, few, fr.FR_SDF_U8, 1, fr.FR_SAMPLE_CENTER)
+        out2.zero_(); torch.cuda.synchronize()
+        p2.render(out2.data_ptr(), W, H); ctx.sync()
+        p2.close()
+    finally:
+        ctx.set_option("sdf_cull", 1)
+    assert torch.equal(out2[:1024], first[:1024])                       # (32 cells = two cell rows)
+    host = first.cpu().numpy()
+    for k in (5, 37, 200, 383):
+        ref = np.zeros((cell, cell), np.uint8)
+        one = jobs[k:k + 1].copy()
+        one["out_x"] = 0; one["out_y"] = 0
+        oracle.render_batch(gs, one, O.SDF_U8, ref, 1, True, 16)
+        y, x = int(jobs["out_y"][k]), int(jobs["out_x"][k])
+        assert np.array_equal(host[y:y + cell, x:x + cell], ref), k
+    dgs.close()
+    assert 0.0 < float((first == 0).float().mean()) < 1.0 and 0.0 < float((first == 255).float().mean()) < 1.0
