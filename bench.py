@@ -10,8 +10,8 @@ contiguous glyph range and its own atlas band — no collective on the data path
 N > 1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
 (one rank per GPU, RCCL); bench.py never spawns ranks itself.  Weak scaling by default (the workload's
 glyph count PER GPU); `--total-glyphs T` fixes the job size instead (strong scaling: configs[3] /
-configs[4] are fixed-size jobs).  With N > 1 the optional assembly of the atlas bands is timed too (one
-all_gather_into_tensor, reported separately: gather_ms / gather_GBps — never part of `value`; --no-gather skips it).
+configs[4] are fixed-size jobs).  With N > 1 the optional assembly of the atlas bands is timed too, in both forms —
+gather onto rank 0 and all-gather — reported separately under "gather", never part of `value` (--no-gather skips it).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md §7 for every field's derivation."""
 import argparse
@@ -163,7 +163,7 @@ def main():
             dist.init_process_group(backend)
 
     import font_renderer_amd as fr
-    from font_renderer_amd.shard import gather_atlas, gather_buffer, shard_range
+    from font_renderer_amd.shard import shard_range
 
     wl = dict(WORKLOADS[args.workload])
     if args.glyphs:
@@ -199,10 +199,11 @@ def main():
         ctx.set_option(k, int(v))
     # the atlas band lives inside the gather destination when the gather is timed (no staging copy)
     gbuf = None
-    if world > 1 and not args.no_gather and backend == "nccl" and wl.get("gen", "synth") in ("synth", "stroke"):
+    if world > 1 and not args.no_gather:
+        # every rank's band has the same shape in every workload here (equal glyph counts, or the same font): W equal slots
         with torch.cuda.stream(stream):
-            gbuf = gather_buffer(total_glyphs, cell, cols, world, "cuda", torch.int16 if bpp == 2 else torch.uint8)
-            pad = gbuf.shape[0] // world
+            gbuf = torch.empty((world * H, W), dtype=torch.int16 if bpp == 2 else torch.uint8, device="cuda")
+            pad = H
             out = gbuf[rank * pad:rank * pad + H]
             out.zero_()
     else:
@@ -263,25 +264,31 @@ def main():
     # ---- optional assembly of the atlas bands, timed on its own ("gather reported separately")
     gather = None
     if gbuf is not None:
-        try:
-            with torch.cuda.stream(stream):
-                for _ in range(2):
-                    gather_atlas(gbuf[rank * pad:(rank + 1) * pad], total_glyphs, cell, cols, out=gbuf, compact=False)
-                torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-                tg = time.perf_counter()
-                reps = 10
-                for _ in range(reps):
-                    gather_atlas(gbuf[rank * pad:(rank + 1) * pad], total_glyphs, cell, cols, out=gbuf, compact=False)
-                torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-                tg = (time.perf_counter() - tg) / reps
-            t = torch.tensor([tg], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tg = float(t.item())
-            gbytes = gbuf.numel() * gbuf.element_size()
-            gather = {"gather_ms": round(tg * 1e3, 4), "gather_GBps": round(gbytes / tg / 1e9, 2), "gathered_bytes": gbytes,
-                      "collective": f"all_gather_into_tensor ({backend}), every rank receives the whole atlas; not part of `value`"}
-        except Exception as e:                               # the optional assembly must never cost the throughput line
-            gather = {"error": f"{type(e).__name__}: {e}"}
+        from font_renderer_amd.shard import gather_bands
+        gather = {}
+        for form, root in (("to_root0", 0), ("all", None)):
+            try:
+                with torch.cuda.stream(stream):
+                    for _ in range(2):
+                        gather_bands(out, gbuf, root=root)
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                    reps = 10
+                    for _ in range(reps):
+                        gather_bands(out, gbuf, root=root)
+                    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+                    tg = (time.perf_counter() - tg) / reps
+                t = torch.tensor([tg], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tg = float(t.item())
+                gbytes = gbuf.numel() * gbuf.element_size()
+                moved = gbytes * (world - 1) // world if root is not None else gbytes * (world - 1)
+                gather[form] = {"ms": round(tg * 1e3, 4), "atlas_GBps": round(gbytes / tg / 1e9, 2), "atlas_bytes": gbytes,
+                                "bytes_over_xgmi": moved,
+                                "collective": ("dist.gather onto rank 0 (RCCL: a group of point-to-point transfers, each peer's band over its own link)"
+                                               if root is not None else "all_gather_into_tensor (every rank receives the whole atlas)") + "; not part of `value`"}
+            except Exception as e:                           # the optional assembly must never cost the throughput line
+                gather[form] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- roofline of the dominant kernel: its launch duration, HIP events on the launch stream around each launch
     # (fr_plan_render_timed) — what rocprofv3 --kernel-trace reports for the kernel (profiles/r02/*_kernel_stats.csv).

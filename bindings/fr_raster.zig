@@ -68,6 +68,7 @@ pub extern "c" fn fr_plan_pixels(plan: *const fr_plan) u64;
 pub extern "c" fn fr_plan_stats(plan: *const fr_plan, n_jobs_cov4: ?*u32, n_jobs_general: ?*u32) c_int;
 pub extern "c" fn fr_plan_describe(plan: *const fr_plan, buf: [*]u8, cap: usize) c_int;
 pub extern "c" fn fr_allgather_bands(ctx: *fr_ctx, nccl_comm: *anyopaque, atlas_dev: *anyopaque, band_bytes: usize) c_int;
+pub extern "c" fn fr_gather_bands(ctx: *fr_ctx, nccl_comm: *anyopaque, atlas_dev: *anyopaque, band_bytes: usize, root: c_int) c_int;
 pub extern "c" fn fr_render_batch(ctx: *fr_ctx, gs: *const fr_glyphset, jobs: [*]const Job, n_jobs: u32, params: *const RasterParams, out_host: *anyopaque, out_stride: usize, out_rows: usize) c_int;
 // ---- renderGlyph drop-in
 pub extern "c" fn fr_render_glyph_dims(box: *const [4]i16, units_per_em: u16, font_size: u16, min_corner: *[2]i16, max_corner: *[2]i16, width: *u16, height: *u16, scale: ?*f32) c_int;

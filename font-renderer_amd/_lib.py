@@ -57,6 +57,7 @@ SYMBOLS = [
     ("fr_plan_stats", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("fr_plan_describe", C.c_int, [_P, C.c_char_p, C.c_size_t]),
     ("fr_allgather_bands", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("fr_gather_bands", C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     ("fr_render_batch", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(RasterParams), _P, C.c_size_t, C.c_size_t]),
     ("fr_render_glyph_dims", C.c_int, [_P, C.c_uint16, C.c_uint16, _P, _P, C.POINTER(C.c_uint16),
                                        C.POINTER(C.c_uint16), C.POINTER(C.c_float)]),

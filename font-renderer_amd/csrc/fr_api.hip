@@ -813,6 +813,47 @@ int fr_allgather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t ban
     return FR_OK;
 }
 
+// Gather-to-root form of the same assembly (every peer has its own xGMI link to the root, so the root
+// ingests up to 7 links' worth while no rank receives bytes it does not need — an all-gather moves W times the atlas):
+// one RCCL group of point-to-point transfers — the root posts a receive per peer into that peer's slot of its atlas,
+// every other rank one send of its own band.  root < 0: the all-gather above.
+int fr_gather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes, int root)
+{
+    if (root < 0) return fr_allgather_bands(ctx, nccl_comm, atlas_dev, band_bytes);
+    if (!ctx || !nccl_comm || !atlas_dev) return fail(FR_E_INVALID, "fr_gather_bands: NULL argument");
+    if (band_bytes == 0) return FR_OK;
+    using p2p_fn = int (*)(void *, size_t, int, int, void *, hipStream_t);          // ncclSend / ncclRecv (buffer, count, type, peer, comm, stream)
+    using group_fn = int (*)();
+    using count_fn = int (*)(void *, int *);
+    static const auto nsend = reinterpret_cast<p2p_fn>(rccl_symbol("ncclSend"));
+    static const auto nrecv = reinterpret_cast<p2p_fn>(rccl_symbol("ncclRecv"));
+    static const auto gstart = reinterpret_cast<group_fn>(rccl_symbol("ncclGroupStart"));
+    static const auto gend = reinterpret_cast<group_fn>(rccl_symbol("ncclGroupEnd"));
+    static const auto user_rank = reinterpret_cast<nccl_rank_fn>(rccl_symbol("ncclCommUserRank"));
+    static const auto comm_count = reinterpret_cast<count_fn>(rccl_symbol("ncclCommCount"));
+    if (!nsend || !nrecv || !gstart || !gend || !user_rank || !comm_count)
+        return fail(FR_E_UNSUPPORTED, "fr_gather_bands: no RCCL in this process (the host creates the communicator with it)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rank = -1, world = 0;
+    if (user_rank(nccl_comm, &rank) != 0 || comm_count(nccl_comm, &world) != 0 || rank < 0 || world <= 0)
+        return fail(FR_E_INVALID, "fr_gather_bands: ncclCommUserRank / ncclCommCount failed");
+    if (root >= world) return fail(FR_E_INVALID, "fr_gather_bands: root %d of %d ranks", root, world);
+    unsigned char *base = static_cast<unsigned char *>(atlas_dev);
+    int rc = gstart();
+    if (rc == 0) {
+        if (rank == root) {
+            for (int r = 0; r < world && rc == 0; ++r)
+                if (r != root) rc = nrecv(base + (size_t)r * band_bytes, band_bytes, 0 /* ncclInt8 */, r, nccl_comm, ctx->stream);
+        } else {
+            rc = nsend(base + (size_t)rank * band_bytes, band_bytes, 0, root, nccl_comm, ctx->stream);
+        }
+        const int rc2 = gend();
+        if (rc == 0) rc = rc2;
+    }
+    if (rc != 0) return fail(FR_E_HIP, "fr_gather_bands: RCCL returned %d", rc);
+    return FR_OK;
+}
+
 int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
 {
     return plan_launch(plan, out_dev, out_stride, out_rows);

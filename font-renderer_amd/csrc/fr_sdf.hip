@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     __shared__ float s_best[MULTI ? 16u * 64u : 1u];     // per-pixel minima of the region between blocks of segments
     __shared__ float s_xy[64];                  // the region's 32 sample abscissae, then its 32 sample ordinates
     __shared__ uint32_t s_bits[32];             // the sign bits of the region's 32 rows (bit x of word y: pixel (X0 + x, Y0 + y))
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[32 * 32];   // the region's finished bytes, stored at the end as whole 16-byte runs
     uint32_t bid = blockIdx.x;
     const uint32_t rxi = bid % regions_x; bid /= regions_x;
     const uint32_t ryi = bid % regions_y;
@@ -161,9 +162,17 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
     // multiple of 32) — or, for a job of the general kernel, the byte that kernel left in the output
     const uint32_t jb = job_bits ? job_bits[jidx] : 0xffffffffu;
     const bool use_bits = jb != 0xffffffffu;                    // (wave-uniform)
-    if (use_bits && lane < 32u)
-        s_bits[lane] = (Y0 + lane < job.h) ? bits[(size_t)jb + (size_t)(Y0 + lane) * ((job.w + 31u) / 32u) + X0 / 32u] : 0u;
-    uint32_t done = 0u;                          // quads whose bytes are final (wave-uniform, one bit per quad)
+    if (use_bits) {
+        // lane = 16 pixels of one region row (row lane >> 1, half lane & 1): the tile starts as the saturated encoding —
+        // 255 inside / 0 outside, what every pixel farther than the reach from the outline keeps
+        const uint32_t row = lane >> 1;
+        const uint32_t wbits = (Y0 + row < job.h) ? bits[(size_t)jb + (size_t)(Y0 + row) * ((job.w + 31u) / 32u) + X0 / 32u] : 0u;
+        if ((lane & 1u) == 0u) s_bits[row] = wbits;
+        const uint32_t b16 = (wbits >> (16u * (lane & 1u))) & 0xffffu;
+        // four sign bits -> four bytes 0 / 255: 1 + 2^7 + 2^14 + 2^21 puts bit i at bit 8 i
+        auto spread = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 255u; };
+        *reinterpret_cast<uint4 *>(s_tile + 16u * lane) = make_uint4(spread(b16), spread(b16 >> 4), spread(b16 >> 8), spread(b16 >> 12));
+    }
     // A set of sample points is tested as the disc about its box's centre: radius = half the diagonal, plus the
     // pixel test's slack at its farthest corner (see there), plus a margin for the roundings of this very sum.
     // Both maps are monotone in the pixel index, so the corners are the first and last column / row.
@@ -302,9 +311,9 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
                 touched |= 1u << q;
                 continue;
             }
-            done |= 1u << q;
             if (!valid) continue;
-            uint8_t *px = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
+            uint8_t *px = use_bits ? s_tile + ((q >> 2) * 8u + (lane >> 3)) * 32u + (q & 3u) * 8u + (lane & 7u)
+                                   : out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
             // the sign pass: winding != 0 at this sample
             const bool inside = use_bits ? ((s_bits[(q >> 2) * 8u + (lane >> 3)] >> ((q & 3u) * 8u + (lane & 7u))) & 1u) != 0u : *px != 0;
             float d = __builtin_sqrtf(best) * scale;
@@ -315,37 +324,26 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
             *px = (uint8_t)v;
         }
     }
-    if (!use_bits) return;                       // (the sign bytes already ARE the saturated encoding of every other quad)
-    // ---- everything farther than the reach from the outline: the saturated encoding, 255 inside / 0 outside
-    __syncthreads();                             // (one wave; s_bits is written)
-    if (done == 0u) {
-        // the whole region: lane = 16 pixels of one row (row lane >> 1, half lane & 1), one 16-byte store
+    if (!use_bits) return;                       // (the sign bytes already ARE the saturated encoding of every other pixel)
+    // ---- the region leaves as 64 runs of 16 bytes (lane = row lane >> 1, half lane & 1), clipped to the cell
+    __syncthreads();                             // (one wave; the tile is complete)
+    {
         const uint32_t row = lane >> 1, x0 = X0 + 16u * (lane & 1u), y = Y0 + row;
         if (y < job.h && x0 < job.w) {
-            const uint32_t b16 = (s_bits[row] >> (16u * (lane & 1u))) & 0xffffu;
-            // four sign bits -> four bytes 0 / 255: 1 + 2^7 + 2^14 + 2^21 puts bit i at bit 8 i
-            auto spread = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 255u; };
-            const uint32_t w4[4] = {spread(b16), spread(b16 >> 4), spread(b16 >> 8), spread(b16 >> 12)};
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_tile + 16u * lane);
             uint8_t *dst = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x0;
             if (x0 + 16u <= job.w) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                typedef u32x4 u32x4_u __attribute__((aligned(1)));
-                const u32x4 v = {w4[0], w4[1], w4[2], w4[3]};
-                *reinterpret_cast<u32x4_u *>(dst) = v;
+                typedef u32x4 u32x4_u __attribute__((aligned(4)));      // (global memory takes the unaligned 16-byte store: as c4_store16)
+                const u32x4 w = {v.x, v.y, v.z, v.w};
+                *reinterpret_cast<u32x4_u *>(dst) = w;
             } else {
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (uint32_t i = 0; i < 16u; ++i)
                     if (x0 + i < job.w) dst[i] = (uint8_t)(w4[i >> 2] >> (8u * (i & 3u)));
             }
         }
-        return;
-    }
-    for (uint32_t q = 0; q < 16u; ++q) {
-        if ((done >> q) & 1u) continue;
-        const uint32_t x = X0 + (q & 3u) * 8u + (lane & 7u), y = Y0 + (q >> 2) * 8u + (lane >> 3);
-        if (x < job.w && y < job.h)
-            out[((size_t)job.out_y + y) * out_stride + job.out_x + x] =
-                ((s_bits[(q >> 2) * 8u + (lane >> 3)] >> ((q & 3u) * 8u + (lane & 7u))) & 1u) ? 255u : 0u;
     }
 }
 

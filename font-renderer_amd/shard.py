@@ -3,9 +3,11 @@
 Glyphs are independent (/root/reference/src/tools/render_glyph.zig:24-31 reads only
 its own glyph), so rank r owns the contiguous glyph range [n*r/W, n*(r+1)/W) and
 renders it into its own atlas rows: NO collective on the render path.  The optional
-last step gathers the row bands onto every rank with ONE all_gather_into_tensor into a
-preallocated atlas (RCCL over xGMI on GPUs; gloo in the CPU tests) — equal bands, the
-last one trimmed; no Python list of tensors, no concatenation."""
+last step assembles the row bands in a preallocated atlas (RCCL over xGMI on GPUs; gloo in
+the CPU tests) — equal bands, the last one trimmed, no concatenation: either onto ONE rank
+(root=r: dist.gather into views of the root's atlas — with RCCL a group of point-to-point
+transfers, each peer's bytes crossing its own xGMI link to the root once; SURVEY §5's
+preferred form) or onto every rank (ONE all_gather_into_tensor: W times the ingress)."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -31,6 +33,31 @@ def gather_buffer(n_glyphs: int, cell: int, cols: int, world: int, device, dtype
     """the preallocated destination of gather_atlas: `world` equal bands of the largest band's height"""
     pad = max(band_rows(n_glyphs, cell, cols, world))
     return torch.empty((world * pad, cols * cell), dtype=dtype, device=device)
+
+
+def gather_bands(band: torch.Tensor, out: torch.Tensor, root: Optional[int] = None, group=None) -> Optional[torch.Tensor]:
+    """Equal row bands -> one buffer, for ANY workload (cells, pages, renderGlyph-sized images): `out` is
+    (world * rows, width), `band` is this rank's rows x width — ideally the view out[rank * rows:(rank + 1) * rows] it
+    rendered into (no staging copy).  root=None: all-gather, every rank gets `out`.  root=r: only rank r's `out` is
+    filled (the others may pass any tensor of the right shape, or their own full buffer) -> `out` on the root, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = band.shape[0]
+    assert out.shape[0] == world * rows and out.shape[1:] == band.shape[1:] and out.is_contiguous()
+    if root is None:
+        src = band.contiguous()
+        if dist.get_backend(group) != "nccl":
+            src = src.clone()                     # (only RCCL documents the in-place form: input = own slot of the output)
+        dist.all_gather_into_tensor(out, src, group=group)
+        return out
+    if rank == root:
+        slots = [out[r * rows:(r + 1) * rows] for r in range(world)]
+        mine = slots[rank]
+        if band.data_ptr() != mine.data_ptr():
+            mine.copy_(band)
+        dist.gather(mine if dist.get_backend(group) == "nccl" else mine.clone(), slots, dst=root, group=group)
+        return out
+    dist.gather(band.contiguous(), None, dst=root, group=group)
+    return None
 
 
 def gather_atlas(local_rows: torch.Tensor, n_glyphs: int, cell: int, cols: int, group=None,

@@ -245,6 +245,11 @@ int fr_atlas_layout_glyph_dims(const int16_t *boxes, uint32_t n_glyphs, uint32_t
  * never does); the call binds to the RCCL that is already loaded in the process (dlsym, no link-time dependency) and
  * returns FR_E_UNSUPPORTED if there is none.  Asynchronous like fr_plan_render: fr_ctx_sync / stream order apply.   */
 int fr_allgather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes);
+/* The same assembly onto ONE rank: rank `root` receives every other rank's band into that rank's slot of ITS atlas_dev
+ * (one RCCL group of ncclRecv's), every other rank sends its own band (atlas_dev + rank * band_bytes) and receives
+ * nothing — each peer's bytes cross its own xGMI link to the root once, instead of every rank ingesting the whole atlas.
+ * root < 0 is fr_allgather_bands.  Asynchronous on the context's stream.                                              */
+int fr_gather_bands(fr_ctx *ctx, void *nccl_comm, void *atlas_dev, size_t band_bytes, int root);
 
 /* ---- contour producer (host side): TrueType glyf/loca -> Glyph contour layout ------------
  * What font/Font.zig + font/ttf.zig + font/Glyph.zig do in the reference (Font.initTTF :31,

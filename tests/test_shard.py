@@ -42,6 +42,18 @@ def _worker(rank, world, initfile, outdir, n_glyphs, cell, cols, use_gpu=False):
             oracle_lib.Oracle().render_batch(sub, jobs, oracle_lib.COVERAGE_U8, band, 2, True)
         full = gather_atlas(torch.from_numpy(band), n_glyphs, cell, cols)
         np.save(os.path.join(outdir, f"rank{rank}.npy"), full.numpy())
+        # the gather-to-root form: equal bands into views of the ROOT's buffer; the other rank gets nothing
+        from font_renderer_amd.shard import band_rows, gather_bands
+        pad = max(band_rows(n_glyphs, cell, cols, world))
+        mine = torch.zeros((pad, cols * cell), dtype=torch.uint8)
+        mine[:band.shape[0]] = torch.from_numpy(band)
+        root_out = torch.full((world * pad, cols * cell), 0x5b, dtype=torch.uint8)
+        res = gather_bands(mine, root_out, root=1)
+        assert (res is None) == (rank != 1)
+        if rank == 1:
+            np.save(os.path.join(outdir, "root1.npy"), res.numpy())
+        else:
+            assert bool((root_out == 0x5b).all())                # a non-root rank's buffer is left alone
     finally:
         dist.destroy_process_group()
 
@@ -64,7 +76,15 @@ def _check_two_rank_gather(oracle, n_glyphs, use_gpu):
         initfile = os.path.join(d, "init")
         mp.spawn(_worker, args=(world, initfile, d, n_glyphs, cell, cols, use_gpu), nprocs=world, join=True)
         got = [np.load(os.path.join(d, f"rank{r}.npy")) for r in range(world)]
+        root1 = np.load(os.path.join(d, "root1.npy"))
     assert np.array_equal(got[0], got[1])
+    # gather-to-root: rank 1's buffer holds both bands in their (padded) slots
+    from font_renderer_amd.shard import band_rows
+    rows, pad = band_rows(n_glyphs, cell, cols, world), max(band_rows(n_glyphs, cell, cols, world))
+    at = 0
+    for r in range(world):
+        assert np.array_equal(root1[r * pad:r * pad + rows[r]], got[0][at:at + rows[r]]), r
+        at += rows[r]
     # expected: each rank's band is a cols-wide atlas of its own glyphs, bands stacked in rank order
     import oracle_lib as O
     gs = synth_glyphset(n_glyphs, 24)
@@ -136,6 +156,12 @@ def test_allgather_bands_through_the_c_abi_with_a_one_rank_communicator():
         L.check(lib.fr_allgather_bands(ctx._h, comm, C.c_void_p(band.data_ptr()), band.numel()))
         ctx.sync()
         assert np.array_equal(band.cpu().numpy(), before) and before.max() == 255
+        # the gather-to-root form on the same communicator (root 0 = the only rank: nothing to receive), and root < 0 = all-gather
+        L.check(lib.fr_gather_bands(ctx._h, comm, C.c_void_p(band.data_ptr()), band.numel(), 0))
+        L.check(lib.fr_gather_bands(ctx._h, comm, C.c_void_p(band.data_ptr()), band.numel(), -1))
+        ctx.sync()
+        assert np.array_equal(band.cpu().numpy(), before)
+        assert lib.fr_gather_bands(ctx._h, comm, C.c_void_p(band.data_ptr()), band.numel(), 1) != 0      # root 1 of 1 rank
         # a context without a communicator is refused, not dereferenced
         assert lib.fr_allgather_bands(ctx._h, None, C.c_void_p(band.data_ptr()), band.numel()) != 0
     finally:
