@@ -318,6 +318,37 @@ static int fast_class(const FastRule &R, uint32_t w, uint32_t h, uint32_t nsg, u
     const int rc = (nsg <= 256u && root_bound <= 128u && ray_bound <= 16u) ? 0 : ((nsg <= 256u && root_bound <= 256u) ? 1 : 2);
     return 1 + 3 * (int)(wl - 2u) + rc;
 }
+// classes of fewer than FAST_PART_MIN jobs move up into the next class that has jobs: same strip width and more record
+// slots first, then wider strips with at least as many record slots (class c = 3 (wlog - 2) + record class; cls[j] = c + 1)
+enum { FAST_PART_MIN = 64 };
+static void merge_small_classes(uint32_t counts[9], uint8_t *cls, uint32_t n_jobs)
+{
+    int remap[9];
+    bool any = false;
+    for (int c = 0; c < 9; ++c) {
+        remap[c] = c;
+        if (counts[c] == 0 || counts[c] >= (uint32_t)FAST_PART_MIN) continue;
+        const int w = c / 3, r = c % 3;
+        int target = -1;
+        for (int w2 = w; w2 < 3 && target < 0; ++w2)
+            for (int r2 = (w2 == w ? r + 1 : r); r2 < 3; ++r2)
+                if (counts[3 * w2 + r2]) { target = 3 * w2 + r2; break; }
+        if (target < 0) continue;
+        counts[target] += counts[c];          // (the target may be small itself: it is looked at later in this loop)
+        counts[c] = 0;
+        remap[c] = target;
+        any = true;
+    }
+    if (!any) return;
+    for (int c = 0; c < 9; ++c) {             // chains: a -> b -> c
+        int t = remap[c];
+        while (remap[t] != t) t = remap[t];
+        remap[c] = t;
+    }
+    for (uint32_t j = 0; j < n_jobs; ++j)
+        if (cls[j]) cls[j] = (uint8_t)(remap[cls[j] - 1] + 1);
+}
+
 // the fast jobs of `order` (already grouped by class, `counts[c]` jobs of class c + 1) -> the plan's launches
 static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[9], int ns)
 {
@@ -534,6 +565,11 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
             cls[j] = (uint8_t)fast_class(rule, jb.w, jb.h, nsg, gs->h_root_bound[jb.glyph], gs->h_ray_bound[jb.glyph]);
             if (cls[j]) { ++counts[cls[j] - 1]; ++n_fast; }
         }
+        // A class with only a handful of jobs is not worth a launch of its own (a real font at renderGlyph's sizes: three or
+        // four glyphs per odd class, each launch a few microseconds on the second stream): its jobs join the next class up
+        // that exists — wider strips and / or more record slots render the same bytes (the stores are clipped, spare
+        // record slots stay empty), only a little less efficiently.
+        merge_small_classes(counts, cls.data(), n_jobs);
         uint32_t at[10], run = 0;
         for (int c = 0; c < 9; ++c) { at[c + 1] = run; run += counts[c]; }
         at[0] = run;                                                      // the general kernel's jobs go last
