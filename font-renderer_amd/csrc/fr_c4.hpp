@@ -14,22 +14,28 @@ namespace fr {
 #ifndef FR_C4_PCAP
 #define FR_C4_PCAP 448
 #endif
-#ifndef FR_C4_LSTRIDE
-#define FR_C4_LSTRIDE 36
+#ifndef FR_C4_OCC16
+#define FR_C4_OCC16 FR_C4_OCC
 #endif
-// PCAP: (record, row) pairs laid out per round (a multiple of 64).  LSTRIDE: u16 slots per row list — 32 kept + the
-// dump slot + padding; a multiple of 4 (8-byte rows), 16-byte rows when a multiple of 8
-enum { C4_WAVES = FR_C4_WAVES, C4_PCAP = FR_C4_PCAP, C4_LSTRIDE = FR_C4_LSTRIDE };
+// PCAP: (record, row) pairs laid out per round (a multiple of 64).
+enum { C4_WAVES = FR_C4_WAVES, C4_PCAP = FR_C4_PCAP };
+// u16 slots per row list: the CAP crossings a row keeps + the dump slot + padding to a multiple of 4 (8-byte rows).
+// (36 for CAP = 32; the instances that keep 16 or 8 have shorter rows and leave the LDS to more workgroups)
+constexpr uint32_t c4_lstride(int cap) { return (uint32_t)cap + 4u; }
+// waves per SIMD the register allocation is held to: the instances that keep <= 16 crossings per row may take FR_C4_OCC16
+constexpr int c4_occ(int cap) { return cap <= 16 ? FR_C4_OCC16 : FR_C4_OCC; }
 // 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
+template <uint32_t LSTRIDE>
 __device__ __forceinline__ uint4 c4_ld16(const uint16_t *p)
 {
-    if ((C4_LSTRIDE * 2) % 16 == 0) return *reinterpret_cast<const uint4 *>(p);
+    if ((LSTRIDE * 2) % 16 == 0) return *reinterpret_cast<const uint4 *>(p);
     const uint2 a = reinterpret_cast<const uint2 *>(p)[0], b = reinterpret_cast<const uint2 *>(p)[1];
     return make_uint4(a.x, a.y, b.x, b.y);
 }
+template <uint32_t LSTRIDE>
 __device__ __forceinline__ void c4_st16(uint16_t *p, uint4 v)
 {
-    if ((C4_LSTRIDE * 2) % 16 == 0) { *reinterpret_cast<uint4 *>(p) = v; return; }
+    if ((LSTRIDE * 2) % 16 == 0) { *reinterpret_cast<uint4 *>(p) = v; return; }
     reinterpret_cast<uint2 *>(p)[0] = make_uint2(v.x, v.y);
     reinterpret_cast<uint2 *>(p)[1] = make_uint2(v.z, v.w);
 }

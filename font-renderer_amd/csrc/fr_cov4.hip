@@ -90,8 +90,9 @@ __device__ unsigned long long g_c4_stats[16];
 #define C4_ABL_NODECODE 0
 #endif
 // LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
-template <int WLOG, int RPL, int NS>
+template <int WLOG, int RPL, int NS, int CAP>
 struct C4Lds {
+    static constexpr uint32_t LSTRIDE = c4_lstride(CAP);
     static constexpr uint32_t NCOL = (16u << WLOG) * (uint32_t)NS;          // sample columns of a strip
     static constexpr uint32_t PRB = 64u / (uint32_t)NS;                     // pixel rows of a wave band (64 sample rows)
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;         // padded cx table
@@ -100,7 +101,7 @@ struct C4Lds {
     static constexpr uint32_t EROW = (16u << WLOG) + 16u;                   // bytes per pixel row of E (one 16-B pad)
     static constexpr uint32_t E = PRB * EROW;
     // walk buffers: lists [64][LSTRIDE] u16 | markers [PCAP] u16 | cy [64] f32 | cnt [64] u32 | roff [256] i16
-    static constexpr uint32_t LISTS = 64u * C4_LSTRIDE * 2u;
+    static constexpr uint32_t LISTS = 64u * LSTRIDE * 2u;
     static constexpr uint32_t OFF_PAIRS = LISTS;
     static constexpr uint32_t OFF_CY = OFF_PAIRS + C4_PCAP * 2u;
     static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
@@ -130,10 +131,11 @@ __device__ __forceinline__ void c4_store_clip(unsigned char *dst, uint4 v, int m
 // keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).  NS: samples per pixel axis,
 // 4 (16 samples per pixel) or 2 (4): a wave band is 64 sample rows = 64 / NS pixel rows.
 template <int WLOG, int CAP, int RPL, int NS>
-__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP), c4_occ(CAP))))
 void cov4_kernel(const RenderArgs A)
 {
-    using L = C4Lds<WLOG, RPL, NS>;
+    using L = C4Lds<WLOG, RPL, NS, CAP>;
+    constexpr uint32_t LSTRIDE = L::LSTRIDE;
     static_assert(NS == 4 || NS == 2, "samples per axis");
     constexpr uint32_t RCAP = L::RCAP;
     constexpr uint32_t NW = C4_WAVES;
@@ -199,11 +201,11 @@ void cov4_kernel(const RenderArgs A)
         const uint32_t row_b0 = band * 64u;
         // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
         const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane >> LN))) - sub_off((int)(lane & (uint32_t)(NS - 1)), NS, phase)) / job.scale;
-        uint16_t *mylist = s_lists + lane * C4_LSTRIDE;
+        uint16_t *mylist = s_lists + lane * LSTRIDE;
         {
             const uint4 ones = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
 #pragma unroll
-            for (uint32_t q = 0; q < CAP / 8u; ++q) c4_st16(mylist + 8u * q, ones);
+            for (uint32_t q = 0; q < CAP / 8u; ++q) c4_st16<LSTRIDE>(mylist + 8u * q, ones);
         }
         s_cy[lane] = cy;
         s_cnt[lane] = 0u;
@@ -318,8 +320,8 @@ void cov4_kernel(const RenderArgs A)
                             }
                             if (livep & (J > 0)) {
                                 const uint32_t pos = atomicAdd(&s_cnt[row & 63u], 1u);
-                                uint16_t *rowlist = s_lists + __umul24(row & 63u, (uint32_t)C4_LSTRIDE);
-                                rowlist[min(pos, 32u)] = (uint16_t)(((uint32_t)J << 2) | code);
+                                uint16_t *rowlist = s_lists + __umul24(row & 63u, LSTRIDE);
+                                rowlist[min(pos, (uint32_t)CAP)] = (uint16_t)(((uint32_t)J << 2) | code);   // (slot CAP: the dump)
                             }
                         };
 #if defined(FR_C4_KINDS)
@@ -366,7 +368,7 @@ void cov4_kernel(const RenderArgs A)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint4 v = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
-                if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = c4_ld16(mylist + 8 * q);
+                if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = c4_ld16<LSTRIDE>(mylist + 8 * q);
                 d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
             }
         }
@@ -475,25 +477,59 @@ void cov4_kernel(const RenderArgs A)
                 for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
                     reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
                 c4_wave_lds_sync();
+                // The records that hold the row are a few dozen of up to 64 RPL, scattered over the lanes' RPL slots: walking
+                // the slots would run RPL divergent evaluations at a few per cent of the lanes each.  Instead every hit
+                // is pushed to a dense lane first (ds_permute: a forward permutation, no LDS memory) — slot i's hits go
+                // to the dense positions base .. base + c - 1, its other lanes fill the rest of the same permutation —
+                // and the evaluation runs once per 64 hits.
+                auto evaluate = [&](uint32_t k) {
+                    const Rec40 rk = s_rec[k];
+                    const bool lin = (int32_t)rk.fr < 0;
+                    const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                    const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                    const float t = div_by_int(num, rk.a, rk.rden);
+                    const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                    const float dy = rk.a * t - rk.b;
+                    const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
+                    int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
+                    if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
+                        while (s_cxp[J + 1] <= xx) ++J;
+                        while (s_cxp[J] > xx) --J;
+                    }
+                    if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
+                };
+                unsigned long long hm[RPL];
+                uint32_t total = 0u;
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
-                    if (rra[i] <= grow && grow < rre[i]) {                  // the rows that accept this root (exact)
-                        const Rec40 rk = s_rec[per * lane + (uint32_t)i];
-                        const bool lin = (int32_t)rk.fr < 0;
-                        const float delta = cy_r * rk.a + rk.c1 - rk.c2;
-                        const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
-                        const float t = div_by_int(num, rk.a, rk.rden);
-                        const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
-                        const float dy = rk.a * t - rk.b;
-                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
-                        int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                        const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
-                        if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
-                            while (s_cxp[J + 1] <= xx) ++J;
-                            while (s_cxp[J] > xx) --J;
-                        }
-                        if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
+                    hm[i] = __ballot(rra[i] <= grow && grow < rre[i]);      // the rows that accept this root (exact)
+                    total += (uint32_t)__popcll(hm[i]);
+                }
+                if (__builtin_expect(total <= 128u, 1)) {
+                    uint32_t fill = 0u;                                     // dense positions in use
+                    uint32_t kd0 = 0xffffffffu, kd1 = 0xffffffffu;          // my dense record index: positions 0 .. 63 / 64 .. 127
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        if (hm[i] == 0ull) continue;                        // (wave-uniform)
+                        const bool hit = (hm[i] >> lane) & 1ull;
+                        const uint32_t c = (uint32_t)__popcll(hm[i]);
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[i], 0u));
+                        // hits -> dense positions fill + rank (lane = position mod 64), the other lanes -> the lanes left over
+                        const uint32_t dst = hit ? ((fill + below) & 63u) : ((fill + c + (lane - below)) & 63u);
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(hit ? per * lane + (uint32_t)i : 0xffffffffu));
+                        const uint32_t end = fill + c;
+                        kd0 = (lane >= fill && lane < end) ? got : kd0;
+                        kd1 = (lane + 64u >= fill && lane + 64u < end) ? got : kd1;
+                        fill = end;
                     }
+                    if (kd0 != 0xffffffffu) evaluate(kd0);
+                    if (fill > 64u) { if (kd1 != 0xffffffffu) evaluate(kd1); }
+                } else {
+                    // (more than 128 records hold the row: slot by slot, as they sit)
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i)
+                        if ((hm[i] >> lane) & 1ull) evaluate(per * lane + (uint32_t)i);
                 }
                 c4_wave_lds_sync();
                 int wl[16], tot = 0;
@@ -605,7 +641,6 @@ uint32_t cov4_max_segments() { return 384u; }     // (with 512 record slots; 256
 template <int WLOG, int RPL, int NS>
 static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
-    const size_t lds = C4Lds<WLOG, RPL, NS>::TOTAL + a.lds_pad;
     // glyphs of <= 128 candidate roots (RPL == 2) all but never put more than 16 crossings on a sample row (a real font:
     // 1 row in 100 000): their instance keeps 16 per row in registers — half the list to initialise, pull and sort, 5 %
     // faster — and the rare fuller row takes the direct sum like any over-full row
@@ -614,6 +649,7 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
     // the instance as rocprofv3 names it
     if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, %d, %d, %d>", WLOG, cap, RPL, NS);
     if (!grid.x) return hipSuccess;                // (name only)
+    const size_t lds = (cap == 8 ? C4Lds<WLOG, RPL, NS, 8>::TOTAL : (cap == 16 ? C4Lds<WLOG, RPL, NS, 16>::TOTAL : C4Lds<WLOG, RPL, NS, 32>::TOTAL)) + a.lds_pad;
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {                   // (the 512-record instance; below that the default limit is enough)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
