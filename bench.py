@@ -40,6 +40,7 @@ WORKLOADS = {
     "c2_ascii95_128px_s32_16spp_x64pages": dict(glyphs=95 * 64, cell=128, segs=32, n=4, cols=16, gen="pages", per_page=95, page_rows=16),
     # BASELINE.json configs[3] per-GPU share (BMP/8 = 7936 glyphs, 128^2, 16 samples)
     "c4_bmp_shard_128px_s32_16spp": dict(glyphs=7936, cell=128, segs=32, n=4, cols=64),
+    "c4_bmp_shard_128px_s32_gray_debug": dict(glyphs=7936, cell=128, segs=32, n=1, cols=64, mode="gray_debug"),
     # BASELINE.json configs[4] per-GPU share (4 096 glyphs / 8 = 512, 512^2 cells): build-defined SDF, 1 sample
     "c5_sdf_shard_512px_s64": dict(glyphs=512, cell=512, segs=64, n=1, cols=16, mode="sdf"),
     # SURVEY §8(d) segment list {16, 32, 64, 128, 256}: the C3 shape at the other segment counts
@@ -47,6 +48,10 @@ WORKLOADS = {
     "c3_cjk21k_256px_s64_16spp": dict(glyphs=20992, cell=256, segs=64, n=4, cols=64),
     "c3_cjk21k_256px_s32_16spp": dict(glyphs=20992, cell=256, segs=32, n=4, cols=64),
     "c3_cjk21k_256px_s16_16spp": dict(glyphs=20992, cell=256, segs=16, n=4, cols=64),
+    # 2 x 2 samples per pixel (cov4_kernel<.., 2>)
+    "c3_cjk21k_256px_s128_4spp": dict(glyphs=20992, cell=256, segs=128, n=2, cols=64),
+    # glyphs too large for the fast kernels (512 segments > 384): what is left on the general render_kernel
+    "big_s512_2048cells_256px_16spp": dict(glyphs=2048, cell=256, segs=512, n=4, cols=64),
     # stroke-dense outlines: 8-16 thin strokes per glyph, 10-30 crossings per ray (synth.stroke_glyph)
     "c3_strokes21k_256px_s128_16spp": dict(glyphs=20992, cell=256, segs=128, n=4, cols=64, gen="stroke"),
     # a real font through the C-side contour producer (fr_font_*): every glyph of DejaVuSerif-Italic the

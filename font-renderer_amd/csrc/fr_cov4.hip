@@ -131,7 +131,7 @@ __device__ __forceinline__ void c4_store_clip(unsigned char *dst, uint4 v, int m
 // keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).  NS: samples per pixel axis,
 // 4 (16 samples per pixel) or 2 (4): a wave band is 64 sample rows = 64 / NS pixel rows.
 template <int WLOG, int CAP, int RPL, int NS>
-__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP), c4_occ(CAP))))
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP, WLOG), c4_occ(CAP, WLOG))))
 void cov4_kernel(const RenderArgs A)
 {
     using L = C4Lds<WLOG, RPL, NS, CAP>;

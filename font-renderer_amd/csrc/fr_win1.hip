@@ -70,7 +70,7 @@ __device__ __forceinline__ void w1_store_clip(unsigned char *dst, uint4 a, uint4
 }
 
 template <int WLOG, int MODE, int RPL>
-__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(FR_C4_OCC, FR_C4_OCC)))
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(w1_occ(RPL, WLOG), w1_occ(RPL, WLOG))))
 void win1_kernel(const RenderArgs A)
 {
     using L = W1Lds<WLOG, RPL>;
