@@ -25,12 +25,13 @@ enum { C4_WAVES = FR_C4_WAVES, C4_PCAP = FR_C4_PCAP };
 // u16 slots per row list: the CAP crossings a row keeps + the dump slot + padding to a multiple of 4 (8-byte rows).
 // (36 for CAP = 32; the instances that keep 16 or 8 have shorter rows and leave the LDS to more workgroups)
 constexpr uint32_t c4_lstride(int cap) { return (uint32_t)cap + 4u; }
-// Waves per SIMD the register allocation is held to.  The instances of 64- / 128-pixel strips that keep <= 16 crossings per
-// row (glyphs of <= 128 candidate roots: ASCII-like) need 24 KB of LDS per workgroup, so SIX workgroups fit a CU if
-// the kernel stays within 80 VGPRs: measured on configs[3]'s shard (128^2 cells) 0.0754 -> 0.0643 ms — and nothing at five
-// (an odd number of waves per SIMD: DESIGN.md section 4.0).  The 256-pixel strips are bound to four by their LDS.
-constexpr int c4_occ(int cap, int wlog) { return (cap <= 16 && wlog <= 3) ? FR_C4_OCC_SMALL : FR_C4_OCC; }
-constexpr int w1_occ(int rpl, int wlog) { return (rpl == 2 && wlog <= 3) ? FR_W1_OCC_SMALL : FR_C4_OCC; }
+// Waves per SIMD the register allocation is held to.  The instances that keep <= 16 crossings per row with two records
+// per lane (glyphs of <= 128 candidate roots: ASCII-like, a real font) need <= 26 KB of LDS per workgroup, so SIX
+// workgroups fit a CU if the kernel stays within 80 VGPRs: measured 0.0754 -> 0.0643 ms on configs[3]'s shard (128^2
+// cells), 0.343 -> 0.291 ms on 256^2 cells of 32 segments — and nothing at five (an odd number of waves per SIMD: DESIGN.md
+// section 4.0).  The instances that keep 32 crossings or more records are bound to four (three) by their LDS.
+constexpr int c4_occ(int cap, int wlog, int rpl) { return (cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC; }
+constexpr int w1_occ(int rpl, int wlog) { return (rpl == 2) ? FR_W1_OCC_SMALL : FR_C4_OCC; }
 // 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
 template <uint32_t LSTRIDE>
 __device__ __forceinline__ uint4 c4_ld16(const uint16_t *p)

@@ -107,7 +107,10 @@ struct C4Lds {
     static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
     static constexpr uint32_t OFF_ROFF = OFF_CNT + 256u;
     static constexpr uint32_t WALK = OFF_ROFF + RCAP * 2u;
-    static constexpr uint32_t WAVE = (WALK > E + NCOL * 2u ? WALK : E + NCOL * 2u);   // (E + an over-full row's 16-bit differences)
+    // a row of 16-bit winding differences for an over-full sample row — only where 32 crossings are kept: the instances
+    // that keep <= 16 settle such a row (one in 100 000 there) in registers and leave the LDS to two more workgroups per CU
+    static constexpr uint32_t WD = (CAP <= 16) ? 0u : NCOL * 2u;
+    static constexpr uint32_t WAVE = (WALK > E + WD ? WALK : E + WD);   // (E + an over-full row's 16-bit differences)
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
     static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void c4_store_clip(unsigned char *dst, uint4 v, int m
 // keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).  NS: samples per pixel axis,
 // 4 (16 samples per pixel) or 2 (4): a wave band is 64 sample rows = 64 / NS pixel rows.
 template <int WLOG, int CAP, int RPL, int NS>
-__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP, WLOG), c4_occ(CAP, WLOG))))
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP, WLOG, RPL), c4_occ(CAP, WLOG, RPL))))
 void cov4_kernel(const RenderArgs A)
 {
     using L = C4Lds<WLOG, RPL, NS, CAP>;
@@ -461,44 +464,39 @@ void cov4_kernel(const RenderArgs A)
             if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), (uint32_t)NS);
         }
         if (__builtin_expect(ovf_rows != 0ull, 0)) {
-            // ---- over-full sample rows (more than CAP crossings): the direct sum.  Every record of mine whose row
-            // range holds the row is evaluated once more and adds its step to a row of 16-bit winding DIFFERENCES
-            // in LDS (w(j) = sum over i >= j of d[i]: d[J - 1] += step; the 2 KB next to E, free since the lists
-            // were pulled); a suffix sum (16 columns per lane + one wave scan) gives every sample column's winding,
-            // lane L turns its 4 pixels' non-zero counts into E's difference form (one dword of 4 bytes).
+            // ---- over-full sample rows (more than CAP crossings): the direct sum.  Every record whose row range holds
+            // the row is evaluated once more; the winding of every sample column follows from the (J, step) pairs, and
+            // lane L turns the non-zero counts of its 16 columns' pixels into E's difference form.
+            // Instances that keep 32 crossings (WD != 0): the steps go to a row of 16-bit winding DIFFERENCES in LDS
+            // (w(j) = sum over i >= j of d[i]: d[J - 1] += step; the 2 KB next to E, free since the lists were pulled), a
+            // suffix sum (16 columns per lane + one wave scan) gives the windings.  Instances that keep <= 16 (WD == 0:
+            // glyphs of few crossings per ray — such a row is one in 100 000 there) have no LDS for that row — it is what
+            // lets six of their workgroups share a CU — and broadcast every pair to all lanes instead (v_readlane).
             uint32_t *s_wd = reinterpret_cast<uint32_t *>(wregion + L::E);      // [NCOL / 2] x two int16 fields, bias 0x4000
-            static_assert(L::WAVE >= L::E + NCOL * 2u, "no room for the winding differences of an over-full row");
+            static_assert(L::WD == 0u || L::WAVE >= L::E + NCOL * 2u, "no room for the winding differences of an over-full row");
+            // the reference's evaluation of record k at ray height cy_r -> J (sample columns left of the crossing) and its step
+            auto evaluate = [&](uint32_t k, float cy_r, int &J, uint32_t &step) {
+                const Rec40 rk = s_rec[k];
+                const bool lin = (int32_t)rk.fr < 0;
+                const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                const float t = div_by_int(num, rk.a, rk.rden);
+                const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                const float dy = rk.a * t - rk.b;
+                step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
+                J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
+                if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
+                    while (s_cxp[J + 1] <= xx) ++J;
+                    while (s_cxp[J] > xx) --J;
+                }
+            };
             unsigned long long todo = ovf_rows;
             while (todo) {
                 const uint32_t r = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
                 const uint32_t grow = row_b0 + r;
-                for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
-                    reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
-                c4_wave_lds_sync();
-                // The records that hold the row are a few dozen of up to 64 RPL, scattered over the lanes' RPL slots: walking
-                // the slots would run RPL divergent evaluations at a few per cent of the lanes each.  Instead every hit
-                // is pushed to a dense lane first (ds_permute: a forward permutation, no LDS memory) — slot i's hits go
-                // to the dense positions base .. base + c - 1, its other lanes fill the rest of the same permutation —
-                // and the evaluation runs once per 64 hits.
-                auto evaluate = [&](uint32_t k) {
-                    const Rec40 rk = s_rec[k];
-                    const bool lin = (int32_t)rk.fr < 0;
-                    const float delta = cy_r * rk.a + rk.c1 - rk.c2;
-                    const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
-                    const float t = div_by_int(num, rk.a, rk.rden);
-                    const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
-                    const float dy = rk.a * t - rk.b;
-                    const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;   // +1 or -1 (mod 2^32)
-                    int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
-                    if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
-                        while (s_cxp[J + 1] <= xx) ++J;
-                        while (s_cxp[J] > xx) --J;
-                    }
-                    if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
-                };
                 unsigned long long hm[RPL];
                 uint32_t total = 0u;
 #pragma unroll
@@ -506,54 +504,91 @@ void cov4_kernel(const RenderArgs A)
                     hm[i] = __ballot(rra[i] <= grow && grow < rre[i]);      // the rows that accept this root (exact)
                     total += (uint32_t)__popcll(hm[i]);
                 }
-                if (__builtin_expect(total <= 128u, 1)) {
-                    uint32_t fill = 0u;                                     // dense positions in use
-                    uint32_t kd0 = 0xffffffffu, kd1 = 0xffffffffu;          // my dense record index: positions 0 .. 63 / 64 .. 127
+                int wcol[16];                                               // the winding at my 16 sample columns
+                if constexpr (L::WD != 0u) {
+                    for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
+                        reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
+                    c4_wave_lds_sync();
+                    auto add = [&](uint32_t k) {
+                        int J; uint32_t step;
+                        evaluate(k, cy_r, J, step);
+                        if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
+                    };
+                    // The records that hold the row are a few dozen of up to 64 RPL, scattered over the lanes' RPL slots:
+                    // walking the slots would run RPL divergent evaluations at a few per cent of the lanes each.  Instead
+                    // every hit is pushed to a dense lane first (ds_permute: a forward permutation, no LDS memory) — slot
+                    // i's hits go to the dense positions fill .. fill + c - 1, its other lanes fill the rest of the same
+                    // permutation — and the evaluation runs once per 64 hits.
+                    if (__builtin_expect(total <= 128u, 1)) {
+                        uint32_t fill = 0u;                                 // dense positions in use
+                        uint32_t kd0 = 0xffffffffu, kd1 = 0xffffffffu;      // my dense record index: positions 0 .. 63 / 64 .. 127
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) {
+                            if (hm[i] == 0ull) continue;                    // (wave-uniform)
+                            const bool hit = (hm[i] >> lane) & 1ull;
+                            const uint32_t c = (uint32_t)__popcll(hm[i]);
+                            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[i], 0u));
+                            // hits -> dense positions fill + rank (lane = position mod 64), the other lanes -> the lanes left over
+                            const uint32_t dst = hit ? ((fill + below) & 63u) : ((fill + c + (lane - below)) & 63u);
+                            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(hit ? per * lane + (uint32_t)i : 0xffffffffu));
+                            const uint32_t end = fill + c;
+                            kd0 = (lane >= fill && lane < end) ? got : kd0;
+                            kd1 = (lane + 64u >= fill && lane + 64u < end) ? got : kd1;
+                            fill = end;
+                        }
+                        if (kd0 != 0xffffffffu) add(kd0);
+                        if (fill > 64u) { if (kd1 != 0xffffffffu) add(kd1); }
+                    } else {
+                        // (more than 128 records hold the row: slot by slot, as they sit)
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i)
+                            if ((hm[i] >> lane) & 1ull) add(per * lane + (uint32_t)i);
+                    }
+                    c4_wave_lds_sync();
+                    int tot = 0;
+                    if (16u * lane < NCOL) {
+                        const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
+                        const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                        for (int c = 15; c >= 0; --c) {
+                            tot += (int)((dws[c >> 1] >> (16 * (c & 1))) & 0xffffu) - 0x4000;
+                            wcol[c] = tot;                                  // columns c .. 15 of my 16
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) wcol[c] = 0;
+                    }
+                    const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
+                    const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);   // everything right of my 16 columns
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) wcol[c] += right;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) wcol[c] = 0;
+                    const int col0 = (int)(16u * lane);                     // my first sample column
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) {
                         if (hm[i] == 0ull) continue;                        // (wave-uniform)
-                        const bool hit = (hm[i] >> lane) & 1ull;
-                        const uint32_t c = (uint32_t)__popcll(hm[i]);
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[i], 0u));
-                        // hits -> dense positions fill + rank (lane = position mod 64), the other lanes -> the lanes left over
-                        const uint32_t dst = hit ? ((fill + below) & 63u) : ((fill + c + (lane - below)) & 63u);
-                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)(hit ? per * lane + (uint32_t)i : 0xffffffffu));
-                        const uint32_t end = fill + c;
-                        kd0 = (lane >= fill && lane < end) ? got : kd0;
-                        kd1 = (lane + 64u >= fill && lane + 64u < end) ? got : kd1;
-                        fill = end;
+                        int J = 0; uint32_t step = 0u;
+                        if ((hm[i] >> lane) & 1ull) evaluate(per * lane + (uint32_t)i, cy_r, J, step);
+                        unsigned long long m = hm[i];
+                        while (m) {                                         // every crossing to every lane: w(j) += step [j < J]
+                            const int h = (int)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const int n = __builtin_amdgcn_readlane(J, h) - col0;
+                            const int sh = __builtin_amdgcn_readlane((int)step, h);
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) wcol[c] += (c < n) ? sh : 0;
+                        }
                     }
-                    if (kd0 != 0xffffffffu) evaluate(kd0);
-                    if (fill > 64u) { if (kd1 != 0xffffffffu) evaluate(kd1); }
-                } else {
-                    // (more than 128 records hold the row: slot by slot, as they sit)
-#pragma unroll
-                    for (int i = 0; i < RPL; ++i)
-                        if ((hm[i] >> lane) & 1ull) evaluate(per * lane + (uint32_t)i);
                 }
-                c4_wave_lds_sync();
-                int wl[16], tot = 0;
-                if (16u * lane < NCOL) {
-                    const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
-                    const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-                    for (int c = 15; c >= 0; --c) {
-                        tot += (int)((dws[c >> 1] >> (16 * (c & 1))) & 0xffffu) - 0x4000;
-                        wl[c] = tot;                                        // columns c .. 15 of my 16
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) wl[c] = 0;
-                }
-                const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
-                const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);   // everything right of my 16 columns
                 constexpr int PPL = 16 / NS;                              // pixels of my 16 sample columns
                 int cq[PPL];
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) {
                     cq[q] = 0;
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) cq[q] += (wl[NS * q + c] + right != 0);
+                    for (int c = 0; c < NS; ++c) cq[q] += (wcol[NS * q + c] != 0);
                 }
                 int prev = __shfl_up(cq[PPL - 1], 1);
                 if (lane == 0) prev = 0;

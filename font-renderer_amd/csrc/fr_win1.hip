@@ -30,7 +30,10 @@ struct W1Lds {
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;
     static constexpr uint32_t RCAP = 64u * RPL;
     static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
-    static constexpr uint32_t PCAP = RCAP > 256u ? RCAP : 256u;             // pairs per round (one row has <= RCAP)
+    // pairs per round (one row has <= RCAP).  The two-records-per-lane instances take 128 and settle an over-full row in
+    // registers (below) instead of in the marker array: that is what lets SIX of their workgroups share a CU at 256-pixel strips
+    static constexpr uint32_t PCAP = RCAP > 256u ? RCAP : (RPL == 2 ? 128u : 256u);
+    static constexpr bool WD_LDS = RPL != 2;                                // an over-full row's 16-bit differences live in the marker array
     static constexpr uint32_t EROW = NCOL + 16u;
     static constexpr uint32_t E = W1_ROWS * EROW;
     // per wave: E | markers [PCAP] u16 (later: one row of 16-bit differences) | cy [16] | cnt [16] | roff [RCAP] i16
@@ -272,57 +275,89 @@ void win1_kernel(const RenderArgs A)
         const uint32_t ovf_rows = (uint32_t)(__ballot(cnt > 31u) & 0xffffull);
         if (ovf_rows) {
             uint32_t *s_wd = reinterpret_cast<uint32_t *>(s_pairs);          // [NCOL / 2] x two int16 fields, bias 0x4000
-            static_assert(PCAP * 2u >= NCOL * 2u, "no room for the 16-bit winding differences of a row");
+            static_assert(!L::WD_LDS || PCAP * 2u >= NCOL * 2u, "no room for the 16-bit winding differences of a row");
             uint32_t todo = ovf_rows;
             while (todo) {
                 const uint32_t r = (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
                 const float cy_r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), (int)r));
                 const uint32_t grow = y0 + r;
-                for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
-                    reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
-                c4_wave_lds_sync();
+                // the reference's evaluation of record k at this row -> J (columns left of the crossing) and its step
+                auto evaluate = [&](uint32_t k, int &J, uint32_t &step) {
+                    const Rec40 rk = s_rec[k];
+                    const bool lin = (int32_t)rk.fr < 0;
+                    const float delta = cy_r * rk.a + rk.c1 - rk.c2;
+                    const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
+                    const float t = div_by_int(num, rk.a, rk.rden);
+                    const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
+                    const float dy = rk.a * t - rk.b;
+                    step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;
+                    J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
+                    const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
+                    if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
+                        while (s_cxp[J + 1] <= xx) ++J;
+                        while (s_cxp[J] > xx) --J;
+                    }
+                };
+                int wcol[16];                                               // the winding at my 16 columns
+                if constexpr (L::WD_LDS) {
+                    for (uint32_t q = lane; q < NCOL * 2u / 16u; q += 64u)
+                        reinterpret_cast<uint4 *>(s_wd)[q] = make_uint4(0x40004000u, 0x40004000u, 0x40004000u, 0x40004000u);
+                    c4_wave_lds_sync();
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    if (rra[i] <= grow && grow < rre[i]) {
-                        const Rec40 rk = s_rec[per * lane + (uint32_t)i];
-                        const bool lin = (int32_t)rk.fr < 0;
-                        const float delta = cy_r * rk.a + rk.c1 - rk.c2;
-                        const float num = lin ? (cy_r - rk.b) : (rk.b + sqrt_rn(delta) * rk.sgn);
-                        const float t = div_by_int(num, rk.a, rk.rden);
-                        const float xx = (rk.ax * t + rk.bx) * t + rk.p0x;
-                        const float dy = rk.a * t - rk.b;
-                        const uint32_t step = ((dy > 0.0f) ? ((rk.fr >> 26) & 3u) : ((rk.fr >> 24) & 3u)) - 1u;
-                        int J = (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(xx, jscale, -joff), 0.0f, ncolf);
-                        const float c0 = s_cxp[J], c1 = s_cxp[J + 1];               // one paired read; the guess is nearly always right
-                        if (__builtin_expect(!((c0 <= xx) & (xx < c1)), 0)) {
-                            while (s_cxp[J + 1] <= xx) ++J;
-                            while (s_cxp[J] > xx) --J;
+                    for (int i = 0; i < RPL; ++i) {
+                        if (rra[i] <= grow && grow < rre[i]) {
+                            int J; uint32_t step;
+                            evaluate(per * lane + (uint32_t)i, J, step);
+                            if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
                         }
-                        if (J > 0) atomicAdd(&s_wd[(uint32_t)(J - 1) >> 1], step << (16u * ((uint32_t)(J - 1) & 1u)));
                     }
-                }
-                c4_wave_lds_sync();
-                int wl[16], tot = 0;
-                if (16u * lane < NCOL) {
-                    const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
-                    const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                    c4_wave_lds_sync();
+                    int tot = 0;
+                    if (16u * lane < NCOL) {
+                        const uint4 lo4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane], hi4 = reinterpret_cast<const uint4 *>(s_wd)[2u * lane + 1u];
+                        const uint32_t dws[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
-                    for (int cc = 15; cc >= 0; --cc) {
-                        tot += (int)((dws[cc >> 1] >> (16 * (cc & 1))) & 0xffffu) - 0x4000;
-                        wl[cc] = tot;
+                        for (int cc = 15; cc >= 0; --cc) {
+                            tot += (int)((dws[cc >> 1] >> (16 * (cc & 1))) & 0xffffu) - 0x4000;
+                            wcol[cc] = tot;
+                        }
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < 16; ++cc) wcol[cc] = 0;
                     }
+                    const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
+                    const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc) wcol[cc] += right;
                 } else {
+                    // (two records per lane: glyphs of few crossings per ray — such a row is rare; every crossing is
+                    // broadcast to all lanes, w(j) += step [j < J], no LDS)
 #pragma unroll
-                    for (int cc = 0; cc < 16; ++cc) wl[cc] = 0;
+                    for (int cc = 0; cc < 16; ++cc) wcol[cc] = 0;
+                    const int col0 = (int)(16u * lane);
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        const bool hit = rra[i] <= grow && grow < rre[i];
+                        unsigned long long m = __ballot(hit);
+                        if (m == 0ull) continue;
+                        int J = 0; uint32_t step = 0u;
+                        if (hit) evaluate(per * lane + (uint32_t)i, J, step);
+                        while (m) {
+                            const int h = (int)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const int n = __builtin_amdgcn_readlane(J, h) - col0;
+                            const int sh = __builtin_amdgcn_readlane((int)step, h);
+#pragma unroll
+                            for (int cc = 0; cc < 16; ++cc) wcol[cc] += (cc < n) ? sh : 0;
+                        }
+                    }
                 }
-                const uint32_t incl = c4_wave_incl_add((uint32_t)tot);
-                const int right = (int)((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) - incl);
                 if (MODE == MODE1_BITS) {
                     if (16u * lane < NCOL && r < hlim && 16u * lane + x0s < ((job.w + 31u) & ~31u)) {
                         uint32_t bits16 = 0;
 #pragma unroll
-                        for (int cc = 0; cc < 16; ++cc) bits16 |= (wl[cc] + right != 0 ? 1u : 0u) << cc;
+                        for (int cc = 0; cc < 16; ++cc) bits16 |= (wcol[cc] != 0 ? 1u : 0u) << cc;
                         *reinterpret_cast<uint16_t *>(out_band + (size_t)r * row_bytes + 2u * lane) = (uint16_t)bits16;
                     }
                 } else if (16u * lane < wlim && r < hlim) {
@@ -330,7 +365,7 @@ void win1_kernel(const RenderArgs A)
                     const int mlim = (int)wlim - (int)(16u * lane);
 #pragma unroll
                     for (int cc = 0; cc < 16; ++cc) {
-                        const int w = wl[cc] + right;
+                        const int w = wcol[cc];
                         if (cc >= mlim) continue;
                         if (MODE == MODE1_WINDING_I16) reinterpret_cast<int16_t *>(dst)[cc] = (int16_t)w;
                         else dst[cc] = (unsigned char)((MODE == MODE1_GRAY_DEBUG) ? w1_gray(w) : (w != 0 ? 255u : 0u));

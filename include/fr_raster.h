@@ -107,9 +107,9 @@ int fr_ctx_sync(fr_ctx *ctx);
  * the largest of 64 / 128 / 256 that does not exceed it),
  * "cov4" (0: every job takes the general kernel), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
  * every pixel — the culls are exact, this is how the tests show it), "zero_copy" (1: fr_render_glyph renders small
- * glyphs straight from / into pinned host memory; measured no faster, off by default), "overlap" (0: a plan that
- * needs several kernel launches runs them one after the other on the context's stream instead of forking the
- * smaller ones onto an internal second stream and joining), "min_wgs", "fuse_prepare", "lds_pad"             */
+ * glyphs straight from / into pinned host memory; measured no faster, off by default), "overlap" (a plan that needs several kernel launches forks the
+ * smaller ones onto an internal second stream and joins them: 1 (default) for plans of >= 32 Mpixel — below that one
+ * stream is quicker —, 2 always, 0 never), "min_wgs", "fuse_prepare", "lds_pad"             */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 
 /* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------

@@ -103,6 +103,7 @@ def test_mixed_glyph_sizes_in_one_plan(ctx, oracle):
             st = fr.Plan(fr.DeviceGlyphSet(ctx, gs), jobs, fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER).stats()
             assert st["jobs_cov4"] == len(gs) - 1 and st["jobs_general"] == 1, st
             assert np.array_equal(_render_opt(ctx, gs, jobs, atlas_shape(len(gs), cell, 5), n, True, overlap=0), ref)
+            assert np.array_equal(_render_opt(ctx, gs, jobs, atlas_shape(len(gs), cell, 5), n, True, overlap=2), ref)   # (forked whatever the size)
     jobs = cell_jobs(gs, 64, 64, 2048, 5)
     got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_WINDING_I16, atlas_shape(len(gs), 64, 5), 1, False, threads=16)
     assert np.array_equal(got, ref)
