@@ -351,7 +351,11 @@ void cov4_kernel(const RenderArgs A)
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min(PRB, job.h - y0);
+        #ifdef FR_NO_RAGGED   // timing-only experiment: whole cells only
+        const bool edge = false;
+#else
         const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < SW) | (hlim < PRB))) != 0;
+#endif
         if (__ballot(cnt != 0u) == 0ull) {
             // no crossing on any of my 64 sample rows: every winding is 0 — store the band's background
             for (uint32_t yl = lane >> WLOG; yl < PRB; yl += (64u >> WLOG)) {
@@ -606,9 +610,9 @@ void cov4_kernel(const RenderArgs A)
 
         // ---- windows: lane = one 16-pixel window of one pixel row; integrate, map, one 16-byte store
         constexpr uint32_t K1 = 0x01010101u;
-        if (C4_ABL_KEEP(1))
-#pragma unroll
-        for (uint32_t it = 0; it < (PRB * NWIN) / 64u; ++it) {
+        // (one window pass: the hot form stores whole windows; a band or strip cut by the cell's border runs the same
+        // arithmetic in a loop of its own — rolled, clipped stores — so that the hot loop stays as small as it was)
+        auto window_pass = [&](uint32_t it, auto clipped) {
             const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
             const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
             // inclusive byte prefix inside each dword: bytes 16 (i + 1) + sums; back to a bias of 16 per byte
@@ -652,8 +656,17 @@ void cov4_kernel(const RenderArgs A)
             };
             const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
             unsigned char *dst = out_band + (size_t)prow * A.out_stride + 16u * wx;
-            if (!edge) c4_store16(dst, v);
+            if (!decltype(clipped)::value) c4_store16(dst, v);
             else c4_store_clip(dst, v, prow < hlim ? (int)wlim - (int)(16u * wx) : 0);
+        };
+        if (C4_ABL_KEEP(1)) {
+            if (__builtin_expect(!edge, 1)) {
+#pragma unroll
+                for (uint32_t it = 0; it < (PRB * NWIN) / 64u; ++it) window_pass(it, std::false_type{});
+            } else {
+#pragma clang loop unroll(disable)
+                for (uint32_t it = 0; it < (PRB * NWIN) / 64u; ++it) window_pass(it, std::true_type{});
+            }
         }
         c4_wave_lds_sync();                        // E is the next band's list region
     }

@@ -15,6 +15,7 @@
 // per 4 KB of gray output about half the vector instructions of cov4_kernel's 16-sample pixel.
 #include "fr_c4.hpp"
 #include <cstdio>
+#include <type_traits>
 
 namespace fr {
 
@@ -253,7 +254,11 @@ void win1_kernel(const RenderArgs A)
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
+        #ifdef FR_NO_RAGGED   // timing-only experiment: whole cells only
+        const bool edge = false;
+#else
         const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < NCOL) | (hlim < (uint32_t)W1_ROWS))) != 0;
+#endif
         if ((__ballot(cnt != 0u) & 0xffffull) == 0ull) {
             // no crossing on any of my 16 rows: every winding is 0
             const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
@@ -377,8 +382,10 @@ void win1_kernel(const RenderArgs A)
 
         // ---- windows: lane = 16 pixels of one pixel row; integrate, map, store
         constexpr uint32_t K1 = 0x01010101u;
-#pragma unroll
-        for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) {
+        // (one window pass: the hot form stores whole windows; a band or strip cut by the cell's border runs the same
+        // arithmetic in a loop of its own — rolled, clipped stores — so that the hot loop stays as small as it was)
+        auto window_pass = [&](uint32_t it, auto clipped) {
+            constexpr bool edge = decltype(clipped)::value;
             const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
             const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
             // bytes 32 + d: inclusive prefix inside each dword gives 32 (i + 1) + sums; then a bias of 64 per byte
@@ -405,7 +412,7 @@ void win1_kernel(const RenderArgs A)
             const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
             x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 96 + w
             const uint32_t p0 = x0, p1 = x1, p2 = x2, p3 = x3;              // (pixel order: byte x of the row is pixel x)
-            if ((ovf_rows >> prow) & 1u) continue;                          // stored by the direct path above
+            if ((ovf_rows >> prow) & 1u) return;                            // stored by the direct path above
             unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
             const int mclip = prow < hlim ? (int)wlim - (int)(16u * wx) : 0;   // (edge only) pixels of my window inside the cell
             if (MODE == MODE1_BITS) {
@@ -465,6 +472,13 @@ void win1_kernel(const RenderArgs A)
                 if (edge) w1_store_clip<2u>(dst, va, vb, mclip);
                 else { __builtin_memcpy(dst, &va, 16); __builtin_memcpy(dst + 16, &vb, 16); }
             }
+        };
+        if (__builtin_expect(!edge, 1)) {
+#pragma unroll
+            for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) window_pass(it, std::false_type{});
+        } else {
+#pragma clang loop unroll(disable)
+            for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) window_pass(it, std::true_type{});
         }
         c4_wave_lds_sync();                        // E is re-initialised by the next band
     }
