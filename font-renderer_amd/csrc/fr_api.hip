@@ -107,8 +107,8 @@ struct fr_plan {
     const fr_glyphset *gs = nullptr;
     fr::Job *d_jobs = nullptr;
     uint32_t *d_job_seg = nullptr;     // [n_jobs][2]: first segment and segment count of the job's glyph
-    uint32_t *d_bits = nullptr;        // FR_SDF_U8: the sign bit planes of the fast kernels' jobs (one bit per pixel, rows of
-    uint32_t *d_job_bits = nullptr;    // ceil(w / 32) words) and each job's first word in them (0xffffffff: a general-kernel job)
+    uint32_t *d_bits = nullptr;        // FR_SDF_U8: the sign bit planes of the fast kernels' jobs (one bit per pixel: fr_win1.hip)
+    uint32_t *d_job_bits = nullptr;    // and each job's first word in them (0xffffffff: a general-kernel job)
     uint32_t *d_large = nullptr;       // distinct glyphs of more than 128 segments among the jobs: their records are
     uint32_t n_large = 0;              // rebuilt by prepare_kernel before every render (the others: inside the render kernel)
     uint32_t n_jobs = 0;
@@ -642,7 +642,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         uint64_t words = 0;
         for (uint32_t q = 0; q < n_fast; ++q) {
             jbits[q] = (uint32_t)words;
-            words += (uint64_t)((sorted_jobs[q].w + 31u) / 32u) * sorted_jobs[q].h;
+            words += (uint64_t)((sorted_jobs[q].w + 255u) / 256u) * sorted_jobs[q].h * 8u;      // (one plane per 256-pixel column: h rows of 8 words)
             if (words >= 0xffffffffull) { e = hipErrorInvalidValue; break; }
         }
         if (e == hipSuccess) e = hipMalloc(&p->d_bits, (size_t)(words ? words : 1) * 4);

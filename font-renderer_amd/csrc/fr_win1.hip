@@ -19,9 +19,12 @@
 
 namespace fr {
 
-// MODE1_BITS: the non-zero mask as ONE BIT per pixel in a job-local bit plane (A.out = the plane's base, A.job_bits[j] =
-// the job's first 32-bit word, rows of ceil(w / 32) words, bit x % 32 of word x / 32 = pixel x) — the sign the SDF
-// kernel reads (fr_sdf.hip): an eighth of the bytes of the mask, and the output itself is then written only once
+// MODE1_BITS: the non-zero mask as ONE BIT per pixel in job-local bit planes (A.out = the planes' base, A.job_bits[j] =
+// the job's first 32-bit word) — the sign the SDF kernel reads (fr_sdf.hip): an eighth of the bytes of the mask, and
+// the output itself is then written only once.  Layout: one plane per 256-pixel column of the cell, ceil(w / 256) of
+// them one after the other, each h rows of 8 words (bit x % 32 of word (x % 256) / 32 = pixel x) — so the 16 rows of a
+// band are 512 CONTIGUOUS bytes and one store instruction of a wave (4 rows x 16 windows x 2 bytes) writes one whole
+// 128-byte line (rows of ceil(w / 32) words interleaved the strips of a wide cell: 4.5 x the bytes reached memory)
 enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2, MODE1_BITS = 3 };
 enum { W1_ROWS = 16 };
 
@@ -243,14 +246,14 @@ void win1_kernel(const RenderArgs A)
         }
         c4_wave_lds_sync();
         const uint32_t cnt = s_cnt[lane & 15u] & 0xffffu;
-        // (bit plane: rows of ceil(w / 32) words from the job's first word; a strip starts on a 64-bit boundary)
-        const size_t row_bytes = (MODE == MODE1_BITS) ? (size_t)((job.w + 31u) / 32u) * 4u : (size_t)A.out_stride * ESZ;
+        // (bit planes: 32-byte rows, the plane of 256-pixel column x0s / 256 starts h rows after the previous one)
+        const size_t row_bytes = (MODE == MODE1_BITS) ? (size_t)32u : (size_t)A.out_stride * ESZ;
         unsigned char *const out_band = (MODE == MODE1_BITS)
-            ? reinterpret_cast<unsigned char *>(A.out) + (size_t)A.job_bits[jidx] * 4u + (size_t)y0 * row_bytes + x0s / 8u
+            ? reinterpret_cast<unsigned char *>(A.out) + (size_t)A.job_bits[jidx] * 4u + ((size_t)(x0s / 256u) * job.h + y0) * 32u + (x0s % 256u) / 8u
             : reinterpret_cast<unsigned char *>(A.out) + (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
-        // 16 sign bits of window wx go to bytes 2 wx, 2 wx + 1 of the strip's part of the row — unless the window lies
-        // past the row's last word
-        const bool bits_ok = 16u * wx + x0s < ((job.w + 31u) & ~31u);
+        // 16 sign bits of window wx go to bytes 2 wx, 2 wx + 1 of the strip's part of the row (a window past the cell's
+        // last word still lies inside the row's 32 bytes: written, never read)
+        const bool bits_ok = true;
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
@@ -359,7 +362,7 @@ void win1_kernel(const RenderArgs A)
                     }
                 }
                 if (MODE == MODE1_BITS) {
-                    if (16u * lane < NCOL && r < hlim && 16u * lane + x0s < ((job.w + 31u) & ~31u)) {
+                    if (16u * lane < NCOL && r < hlim) {
                         uint32_t bits16 = 0;
 #pragma unroll
                         for (int cc = 0; cc < 16; ++cc) bits16 |= (wcol[cc] != 0 ? 1u : 0u) << cc;
