@@ -15,7 +15,7 @@
 //                general render_kernel takes, the byte (255 / 0) its 1-sample coverage left in the output
 //   encoding   : u8 = clamp(floor(128 + 16*d + 0.5), 0, 255)   (8 pixels of range either side)
 //
-// Shape: one WAVE (a 64-lane workgroup, no barriers) per 32x32-pixel region of a cell, taken as 16 quads of
+// Shape: one WAVE (a 64-lane workgroup, no barriers) per 64 x 16-pixel region of a cell, taken as 16 quads of
 // 8x8 pixels, one lane per pixel.  The encoding saturates 8 pixels from the outline, so a segment whose
 // bounding box is farther than that from a set of sample points cannot change any of their bytes.  The box
 // is ORIENTED along the chord: B(t) = chord(t) + 2t(1-t) v with v = p1 - (p0 + p2)/2 and 2t(1-t) in [0, 1/2],
@@ -39,7 +39,10 @@
 
 namespace fr {
 
-constexpr uint32_t SDF_REGION = 32u;          // pixels per side of a wave's region: 4 x 4 quads of 8 x 8 pixels
+// a wave's region: 64 x 16 pixels = 8 x 2 quads of 8 x 8 pixels.  Its rows are 64 bytes: the finished region leaves as
+// whole 64-byte runs — the unit the memory side moves — where the 32-byte rows of a 32 x 32 region cost a read of the other
+// half of every run (profiles/r03: 2.8 x the algorithmic bytes moved with 32 x 32 regions)
+constexpr uint32_t SDF_RW = 64u, SDF_RH = 16u, SDF_QX = SDF_RW / 8u;
 constexpr uint32_t SDF_BLOCK = 64u;           // segments read per block, one per lane (48, for 16 waves per CU instead of 13, was no faster: the kernel is VALU-bound)
 constexpr uint32_t SDF_ENTRY = 28u;           // floats per staged segment (7 x 16 bytes):
 // [0..3] p0x p0y Ax Ay   [4..7] tau_x tau_y a_lo a_hi   [8..11] b_lo b_hi Dx Dy (second difference)
@@ -131,46 +134,57 @@ extern "C" int fr_debug_read_sdf_stats(unsigned long long *out4)
     return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sdf_stats), sizeof(g_sdf_stats)) == hipSuccess ? 0 : -2;
 }
 #endif
-// hand-off between the lanes of ONE wave through LDS (the waves of a workgroup never wait for each other here)
-__device__ __forceinline__ void sdf_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-constexpr uint32_t SDF_WAVES = 4u;            // regions side by side per workgroup: 128 x 32 pixels leave as whole 128-byte runs
-
-// one wave, one 32 x 32 region (columns X0 .., rows Y0 ..) of job `jidx`; s_tile: the workgroup's 32 rows x 128 bytes, of
-// which this region owns columns tile_x0 .. tile_x0 + 31
 template <bool MULTI>
-__device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32_t X0, uint32_t Y0, uint32_t lane,
-                                           const uint32_t *__restrict__ job_seg, const int16_t *__restrict__ seg_pts,
-                                           uint8_t *__restrict__ out, uint64_t out_stride, int phase_center, int cull,
-                                           const uint32_t *__restrict__ bits, uint32_t jb, bool use_bits,
-                                           float *s_seg, float *s_best, float *s_xy, uint32_t *s_bits, uint8_t *s_tile, uint32_t tile_x0)
+__global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ job_seg,
+                                                 const int16_t *__restrict__ seg_pts, uint8_t *__restrict__ out,
+                                                 uint64_t out_stride, uint32_t regions_x, uint32_t regions_y,
+                                                 int phase_center, int cull, const uint32_t *__restrict__ bits,
+                                                 const uint32_t *__restrict__ job_bits)
 {
-    constexpr uint32_t TILE_W = 32u * SDF_WAVES;
+    __shared__ __attribute__((aligned(16))) float s_seg[SDF_BLOCK * SDF_ENTRY];
+    __shared__ float s_best[MULTI ? 16u * 64u : 1u];     // per-pixel minima of the region between blocks of segments
+    __shared__ float s_xy[SDF_RW + SDF_RH];     // the region's 64 sample abscissae, then its 16 sample ordinates
+    __shared__ uint32_t s_bits[2u * SDF_RH];    // the sign bits of the region's 16 rows, two words each (bit x % 32 of word 2 y + x / 32: pixel (X0 + x, Y0 + y))
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[SDF_RW * SDF_RH];   // the region's finished bytes, stored at the end as whole 64-byte runs
+    // Workgroups go to the 8 XCDs round-robin by their index, and each XCD has its own L2.  Logical index = the workgroups
+    // of XCD 0 first, then XCD 1's, ...: regions next to each other in x — which read the same lines of the sign bit plane
+    // and the same segments — run on ONE XCD, one after the other, and find those lines in its L2.
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t n = gridDim.x, per = n / 8u, rem = n % 8u, xcd = bid % 8u, slot = bid / 8u;
+        bid = xcd * per + min(xcd, rem) + slot;     // (XCD x holds per + [x < rem] workgroups)
+    }
+    const uint32_t rxi = bid % regions_x; bid /= regions_x;
+    const uint32_t ryi = bid % regions_y;
+    const uint32_t jidx = bid / regions_y;
+    const Job job = jobs[jidx];
+    const uint32_t X0 = rxi * SDF_RW, Y0 = ryi * SDF_RH;
+    if (X0 >= job.w || Y0 >= job.h) return;
+    const uint32_t lane = threadIdx.x;
     const float off = phase_center ? 0.5f : 0.0f;
     const float scale = job.scale;
-    // sample coordinates exactly as renderGlyph's (render_glyph.zig:26-27): lane l < 32 holds the abscissa of the
-    // region's column l, lane 32 + l the ordinate of its row l — one division per lane for the whole region
-    const float xy = lane < 32u ? ((float)(job.min_x + (int32_t)(X0 + lane)) + off) / scale
-                                : ((float)(job.max_y - (int32_t)(Y0 + lane - 32u)) - off) / scale;
-    s_xy[lane] = xy;
-    // the sign: one word of the job's bit planes per region row (X0 is a multiple of 32) — or, for a job of the general
-    // kernel, the byte that kernel left in the output
+    // sample coordinates exactly as renderGlyph's (render_glyph.zig:26-27): lane l holds the abscissa of the region's
+    // column l, lanes 0 .. 15 also the ordinate of its row l
+    const float xs = ((float)(job.min_x + (int32_t)(X0 + lane)) + off) / scale;
+    const float ys = ((float)(job.max_y - (int32_t)(Y0 + (lane & 15u))) - off) / scale;
+    s_xy[lane] = xs;
+    if (lane < SDF_RH) s_xy[SDF_RW + lane] = ys;
+    // the sign: one word of the job's bit plane per region row (the plane's rows are ceil(w / 32) words; X0 is a
+    // multiple of 32) — or, for a job of the general kernel, the byte that kernel left in the output
+    const uint32_t jb = job_bits ? job_bits[jidx] : 0xffffffffu;
+    const bool use_bits = jb != 0xffffffffu;                    // (wave-uniform)
     if (use_bits) {
-        // lane = 16 pixels of one region row (row lane >> 1, half lane & 1): the tile starts as the saturated encoding —
+        // lane = 16 pixels of one region row (row lane >> 2, quarter lane & 3): the tile starts as the saturated encoding —
         // 255 inside / 0 outside, what every pixel farther than the reach from the outline keeps
-        const uint32_t row = lane >> 1;
-        // (one plane per 256-pixel column of the cell, h rows of 8 words each: fr_win1.hip)
-        const uint32_t wbits = (Y0 + row < job.h) ? bits[(size_t)jb + ((size_t)(X0 / 256u) * job.h + (Y0 + row)) * 8u + (X0 % 256u) / 32u] : 0u;
-        if ((lane & 1u) == 0u) s_bits[row] = wbits;
+        // (one plane per 256-pixel column of the cell, h rows of 8 words each: fr_win1.hip; X0 is a multiple of 64.  The four
+        // regions that share these 16 x 32 bytes run on the same XCD, back to back: see the block index below)
+        const uint32_t row = lane >> 2, half = (lane >> 1) & 1u;
+        const uint32_t wbits = (Y0 + row < job.h) ? bits[(size_t)jb + ((size_t)(X0 / 256u) * job.h + (Y0 + row)) * 8u + (X0 % 256u) / 32u + half] : 0u;
+        if ((lane & 1u) == 0u) s_bits[2u * row + half] = wbits;
         const uint32_t b16 = (wbits >> (16u * (lane & 1u))) & 0xffffu;
         // four sign bits -> four bytes 0 / 255: 1 + 2^7 + 2^14 + 2^21 puts bit i at bit 8 i
         auto spread = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 255u; };
-        *reinterpret_cast<uint4 *>(s_tile + row * TILE_W + tile_x0 + 16u * (lane & 1u)) = make_uint4(spread(b16), spread(b16 >> 4), spread(b16 >> 8), spread(b16 >> 12));
+        *reinterpret_cast<uint4 *>(s_tile + 16u * lane) = make_uint4(spread(b16), spread(b16 >> 4), spread(b16 >> 8), spread(b16 >> 12));
     }
     // A set of sample points is tested as the disc about its box's centre: radius = half the diagonal, plus the
     // pixel test's slack at its farthest corner (see there), plus a margin for the roundings of this very sum.
@@ -182,7 +196,7 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
     };
     auto bcast = [](float v, uint32_t src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src)); };
     float rcx, rcy, rrad;
-    disc(bcast(xy, 0), bcast(xy, 31), bcast(xy, 63), bcast(xy, 32), rcx, rcy, rrad);
+    disc(bcast(xs, 0), bcast(xs, SDF_RW - 1u), bcast(ys, SDF_RH - 1u), bcast(ys, 0), rcx, rcy, rrad);
     // 8 pixels is where the encoding saturates; 2 % and one font unit of slack cover every rounding.
     // cull == 0 (ctx option "sdf_cull", tests): no segment is ever dropped or skipped
     const float reach = cull ? 8.0f / scale * 1.02f + 1.0f : 3.0e+37f;
@@ -210,7 +224,7 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
         const unsigned long long km = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(km);
         if (n == 0u && !(last && touched)) continue;
-        sdf_wave_sync();                         // (the previous block's readers are done with the list; s_xy is written)
+        __syncthreads();                         // (one wave: the previous block's readers are done with the list; s_xy is written)
         if (keep) {
             float *e = s_seg + SDF_ENTRY * __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
             const float ax = c[2] - c[0], ay = c[3] - c[1];                                     // A
@@ -233,13 +247,13 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
         }
         if (!have_quads) {                       // (the first block that keeps anything)
             have_quads = true;
-            const uint32_t qc = (lane & 3u) * 8u, qr = 32u + ((lane >> 2) & 3u) * 8u;
+            const uint32_t qc = (lane & (SDF_QX - 1u)) * 8u, qr = SDF_RW + ((lane & 15u) / SDF_QX) * 8u;
             const float xa = s_xy[qc], xb = s_xy[qc + 7u], ya = s_xy[qr + 7u], yb = s_xy[qr];
             qcx = 0.5f * (xa + xb); qcy = 0.5f * (ya + yb);
             qhx = 0.5f * (xb - xa) * 1.001f; qhy = 0.5f * (yb - ya) * 1.001f;
             qpad = 0.5f + 2.0e-6f * (fabsf(qcx) + fabsf(qcy) + qhx + qhy);                  // >= the pixel test's slack anywhere in the quad
         }
-        sdf_wave_sync();
+        __syncthreads();
         // ---- which list entries can reach which quad: lane (g, q) = (lane >> 4, lane & 15) tests the entries
         // g J .. g J + J - 1 against quad q; bit j of `cm` <-> entry g J + j
         const uint32_t J = (n + 3u) >> 2;
@@ -264,7 +278,7 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
         }
         // ---- the region's quads
         for (uint32_t q = 0; q < 16u; ++q) {
-            const uint32_t QX = X0 + (q & 3u) * 8u, QY = Y0 + (q >> 2) * 8u;
+            const uint32_t QX = X0 + (q % SDF_QX) * 8u, QY = Y0 + (q / SDF_QX) * 8u;
             if (QX >= job.w || QY >= job.h) continue;
             unsigned long long mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)q)
                                     | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)cm, (int)(q + 16u)) << J
@@ -274,7 +288,7 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
             if (!mask && !(last && was)) continue;
             const uint32_t x = QX + (lane & 7u), y = QY + (lane >> 3);
             const bool valid = x < job.w && y < job.h;
-            const float qx = s_xy[(q & 3u) * 8u + (lane & 7u)], qy = s_xy[32u + (q >> 2) * 8u + (lane >> 3)];
+            const float qx = s_xy[(q % SDF_QX) * 8u + (lane & 7u)], qy = s_xy[SDF_RW + (q / SDF_QX) * 8u + (lane >> 3)];
             // A computed curve point B(t) - q can leave the box by a few roundings of its three-term sum (each <= half
             // an ulp of a magnitude <= 2^18 for i16 points: < 2^-6 font units, far less relative to a distant sample),
             // and the box's own frame is rounded too (make_obb).  The box the pixel looks at is therefore grown by
@@ -311,10 +325,11 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
                 continue;
             }
             if (!valid) continue;
-            uint8_t *px = use_bits ? s_tile + ((q >> 2) * 8u + (lane >> 3)) * TILE_W + tile_x0 + (q & 3u) * 8u + (lane & 7u)
+            const uint32_t trow = (q / SDF_QX) * 8u + (lane >> 3), tcol = (q % SDF_QX) * 8u + (lane & 7u);     // my pixel in the region
+            uint8_t *px = use_bits ? s_tile + trow * SDF_RW + tcol
                                    : out + ((size_t)job.out_y + y) * out_stride + job.out_x + x;
             // the sign pass: winding != 0 at this sample
-            const bool inside = use_bits ? ((s_bits[(q >> 2) * 8u + (lane >> 3)] >> ((q & 3u) * 8u + (lane & 7u))) & 1u) != 0u : *px != 0;
+            const bool inside = use_bits ? ((s_bits[2u * trow + (tcol >> 5)] >> (tcol & 31u)) & 1u) != 0u : *px != 0;
             float d = __builtin_sqrtf(best) * scale;
             if (!inside) d = -d;
             float v = 16.0f * d + 128.0f;
@@ -323,46 +338,13 @@ __device__ __forceinline__ void sdf_region(const Job &job, uint32_t jidx, uint32
             *px = (uint8_t)v;
         }
     }
-}
-
-// One workgroup = SDF_WAVES waves = SDF_WAVES regions side by side (128 x 32 pixels) of one cell.  The waves run on their own
-// — every hand-off inside a region is within its wave — and meet once, at the end: the finished bytes of the four regions sit
-// in one LDS tile of 32 rows x 128 bytes and leave as whole 128-byte runs (16 bytes per lane, 8 lanes per row), so that no
-// memory line is written in parts (a region's own rows are 32 bytes: written alone they cost a read of the rest of the
-// line — profiles/r03: 2.8 x the algorithmic bytes moved, now 1.3 x).
-// MULTI: some glyph of the batch has more than SDF_BLOCK segments (the minima then wait in LDS between blocks)
-template <bool MULTI>
-__global__ __launch_bounds__(64 * SDF_WAVES) void sdf_kernel(const Job *__restrict__ jobs, const uint32_t *__restrict__ job_seg,
-                                                             const int16_t *__restrict__ seg_pts, uint8_t *__restrict__ out,
-                                                             uint64_t out_stride, uint32_t groups_x, uint32_t regions_y,
-                                                             int phase_center, int cull, const uint32_t *__restrict__ bits,
-                                                             const uint32_t *__restrict__ job_bits)
-{
-    __shared__ __attribute__((aligned(16))) float s_seg[SDF_WAVES][SDF_BLOCK * SDF_ENTRY];
-    __shared__ float s_best[SDF_WAVES][MULTI ? 16u * 64u : 1u];     // per-pixel minima of a region between blocks of segments
-    __shared__ float s_xy[SDF_WAVES][64];       // a region's 32 sample abscissae, then its 32 sample ordinates
-    __shared__ uint32_t s_bits[SDF_WAVES][32];  // the sign bits of a region's 32 rows (bit x of word y: pixel (X0 + x, Y0 + y))
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[32u * 32u * SDF_WAVES];   // 32 rows x 128 bytes
-    uint32_t bid = blockIdx.x;
-    const uint32_t gxi = bid % groups_x; bid /= groups_x;
-    const uint32_t ryi = bid % regions_y;
-    const uint32_t jidx = bid / regions_y;
-    const Job job = jobs[jidx];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t XG = gxi * SDF_REGION * SDF_WAVES, Y0 = ryi * SDF_REGION;
-    if (XG >= job.w || Y0 >= job.h) return;                     // (workgroup-uniform)
-    const uint32_t jb = job_bits ? job_bits[jidx] : 0xffffffffu;
-    const bool use_bits = jb != 0xffffffffu;                    // (workgroup-uniform)
-    const uint32_t X0 = XG + wave * SDF_REGION;
-    if (X0 < job.w)
-        sdf_region<MULTI>(job, jidx, X0, Y0, lane, job_seg, seg_pts, out, out_stride, phase_center, cull, bits, jb, use_bits,
-                          s_seg[wave], s_best[wave], s_xy[wave], s_bits[wave], s_tile, wave * SDF_REGION);
-    if (!use_bits) return;                       // (a general-kernel job: its sign bytes already ARE the saturated encoding elsewhere)
-    __syncthreads();                             // the four regions' bytes are in the tile
+    if (!use_bits) return;                       // (the sign bytes already ARE the saturated encoding of every other pixel)
+    // ---- the region leaves as 16 runs of 64 bytes (lane = 16 bytes: row lane >> 2, quarter lane & 3), clipped to the cell
+    __syncthreads();                             // (one wave; the tile is complete)
     {
-        const uint32_t t = threadIdx.x, row = t >> 3, x0 = XG + 16u * (t & 7u), y = Y0 + row;
+        const uint32_t row = lane >> 2, x0 = X0 + 16u * (lane & 3u), y = Y0 + row;
         if (y < job.h && x0 < job.w) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(s_tile + 16u * t);
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_tile + 16u * lane);
             uint8_t *dst = out + ((size_t)job.out_y + y) * out_stride + job.out_x + x0;
             if (x0 + 16u <= job.w) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -382,14 +364,14 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_kernel(const Job *__restri
 hipError_t launch_sdf(const RenderArgs &a, uint32_t max_w, uint32_t max_h, uint32_t max_seg, int cull, hipStream_t stream)
 {
     if (a.n_jobs == 0 || max_w == 0 || max_h == 0) return hipSuccess;
-    const uint32_t rx = (max_w + SDF_REGION * SDF_WAVES - 1u) / (SDF_REGION * SDF_WAVES), ry = (max_h + SDF_REGION - 1u) / SDF_REGION;
+    const uint32_t rx = (max_w + SDF_RW - 1u) / SDF_RW, ry = (max_h + SDF_RH - 1u) / SDF_RH;
     const size_t grid = (size_t)a.n_jobs * rx * ry;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     if (max_seg > SDF_BLOCK)
-        hipLaunchKernelGGL(sdf_kernel<true>, dim3((uint32_t)grid), dim3(64 * SDF_WAVES), 0, stream, a.jobs, a.job_seg, a.seg_pts,
+        hipLaunchKernelGGL(sdf_kernel<true>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
                            reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull, a.bits, a.job_bits);
     else
-        hipLaunchKernelGGL(sdf_kernel<false>, dim3((uint32_t)grid), dim3(64 * SDF_WAVES), 0, stream, a.jobs, a.job_seg, a.seg_pts,
+        hipLaunchKernelGGL(sdf_kernel<false>, dim3((uint32_t)grid), dim3(64), 0, stream, a.jobs, a.job_seg, a.seg_pts,
                            reinterpret_cast<uint8_t *>(a.out), a.out_stride, rx, ry, a.phase_center, cull, a.bits, a.job_bits);
     return hipGetLastError();
 }

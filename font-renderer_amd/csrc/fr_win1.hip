@@ -23,8 +23,10 @@ namespace fr {
 // the job's first 32-bit word) — the sign the SDF kernel reads (fr_sdf.hip): an eighth of the bytes of the mask, and
 // the output itself is then written only once.  Layout: one plane per 256-pixel column of the cell, ceil(w / 256) of
 // them one after the other, each h rows of 8 words (bit x % 32 of word (x % 256) / 32 = pixel x) — so the 16 rows of a
-// band are 512 CONTIGUOUS bytes and one store instruction of a wave (4 rows x 16 windows x 2 bytes) writes one whole
-// 128-byte line (rows of ceil(w / 32) words interleaved the strips of a wide cell: 4.5 x the bytes reached memory)
+// band of a 256-pixel strip are 512 CONTIGUOUS bytes, which leave as 32 lanes x 16 bytes in one store instruction.
+// (Measured, WRITE_SIZE per launch for 16.8 MB of bit planes: rows of ceil(w / 32) words written 2 bytes per window
+// 76 MB; this layout written 2 bytes per window 49 MB, 16 bytes per every eighth lane 112 MB, whole 512-byte runs 23 MB;
+// one plane per 64-pixel column in whole 128-byte lines 76 MB.)
 enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2, MODE1_BITS = 3 };
 enum { W1_ROWS = 16 };
 
@@ -74,6 +76,18 @@ __device__ __forceinline__ void w1_store_clip(unsigned char *dst, uint4 a, uint4
         if (ESZ == 2u) reinterpret_cast<uint16_t *>(dst)[i] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
         else dst[i] = (unsigned char)(w[i >> 2] >> (8 * (i & 3)));
     }
+}
+
+// Sign bits of one row of a narrow strip (64 / 128 pixels) or of a row the direct path settled: lane `wx` of the row's
+// consecutive lanes holds the 16 bits of its window; four windows are gathered across the lanes and stored as 8 bytes by
+// every fourth lane.  Every lane of the wave must call this (the gather reads its neighbours); `row` = the first byte of
+// the strip's part of the row in the bit plane, `ok` = the row lies in the cell.
+template <int WLOG>
+__device__ __forceinline__ void w1_store_bits(unsigned char *row, uint32_t wx, uint32_t bits16, bool ok)
+{
+    const uint32_t pair = bits16 | ((uint32_t)__shfl_down((int)bits16, 1) << 16);           // windows wx, wx + 1 (even wx)
+    const uint32_t d1 = (uint32_t)__shfl_down((int)pair, 2);
+    if (ok && (wx & 3u) == 0u) { const uint2 v = make_uint2(pair, d1); __builtin_memcpy(row + 2u * wx, &v, 8); }
 }
 
 template <int WLOG, int MODE, int RPL>
@@ -251,9 +265,8 @@ void win1_kernel(const RenderArgs A)
         unsigned char *const out_band = (MODE == MODE1_BITS)
             ? reinterpret_cast<unsigned char *>(A.out) + (size_t)A.job_bits[jidx] * 4u + ((size_t)(x0s / 256u) * job.h + y0) * 32u + (x0s % 256u) / 8u
             : reinterpret_cast<unsigned char *>(A.out) + (((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s) * ESZ;
-        // 16 sign bits of window wx go to bytes 2 wx, 2 wx + 1 of the strip's part of the row (a window past the cell's
+        // (16 sign bits of window wx go to bytes 2 wx, 2 wx + 1 of the strip's part of the row; a window past the cell's
         // last word still lies inside the row's 32 bytes: written, never read)
-        const bool bits_ok = true;
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
@@ -266,9 +279,15 @@ void win1_kernel(const RenderArgs A)
             // no crossing on any of my 16 rows: every winding is 0
             const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
             const uint4 v = make_uint4(bg, bg, bg, bg);
+            if (MODE == MODE1_BITS && WLOG == 4) {
+                // (a 256-pixel strip: the band's 512 bytes of sign bits in one store instruction, as below)
+                if (lane < 32u && (lane >> 1) < hlim) { const uint4 z = make_uint4(0, 0, 0, 0); __builtin_memcpy(out_band + 16u * lane, &z, 16); }
+                c4_wave_lds_sync();
+                continue;
+            }
             for (uint32_t yl = lane >> WLOG; yl < W1_ROWS; yl += (64u >> WLOG)) {
                 if (MODE == MODE1_BITS) {
-                    if (yl < hlim && bits_ok) *reinterpret_cast<uint16_t *>(out_band + (size_t)yl * row_bytes + 2u * wx) = 0;
+                    w1_store_bits<WLOG>(out_band + (size_t)yl * row_bytes, wx, 0u, yl < hlim);
                     continue;
                 }
                 unsigned char *dst = out_band + (size_t)yl * row_bytes + 16u * ESZ * wx;
@@ -362,12 +381,11 @@ void win1_kernel(const RenderArgs A)
                     }
                 }
                 if (MODE == MODE1_BITS) {
-                    if (16u * lane < NCOL && r < hlim) {
-                        uint32_t bits16 = 0;
+                    uint32_t bits16 = 0;
 #pragma unroll
-                        for (int cc = 0; cc < 16; ++cc) bits16 |= (wcol[cc] != 0 ? 1u : 0u) << cc;
-                        *reinterpret_cast<uint16_t *>(out_band + (size_t)r * row_bytes + 2u * lane) = (uint16_t)bits16;
-                    }
+                    for (int cc = 0; cc < 16; ++cc) bits16 |= (wcol[cc] != 0 ? 1u : 0u) << cc;
+                    // (lanes 0 .. NCOL / 16 - 1 are the row's windows in order)
+                    w1_store_bits<WLOG>(out_band + (size_t)r * row_bytes, lane, bits16, 16u * lane < NCOL && r < hlim);
                 } else if (16u * lane < wlim && r < hlim) {
                     unsigned char *dst = out_band + (size_t)r * row_bytes + 16u * ESZ * lane;
                     const int mlim = (int)wlim - (int)(16u * lane);
@@ -387,6 +405,7 @@ void win1_kernel(const RenderArgs A)
         constexpr uint32_t K1 = 0x01010101u;
         // (one window pass: the hot form stores whole windows; a band or strip cut by the cell's border runs the same
         // arithmetic in a loop of its own — rolled, clipped stores — so that the hot loop stays as small as it was)
+        uint32_t band_bits[(W1_ROWS * NWIN) / 64u];                         // (sign-bit mode, 256-pixel strips: my windows' bits, staged below)
         auto window_pass = [&](uint32_t it, auto clipped) {
             constexpr bool edge = decltype(clipped)::value;
             const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
@@ -415,7 +434,8 @@ void win1_kernel(const RenderArgs A)
             const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
             x0 += cb4; x1 += cb4; x2 += cb4; x3 += cb4;                     // bytes: 96 + w
             const uint32_t p0 = x0, p1 = x1, p2 = x2, p3 = x3;              // (pixel order: byte x of the row is pixel x)
-            if ((ovf_rows >> prow) & 1u) return;                            // stored by the direct path above
+            const bool direct = (ovf_rows >> prow) & 1u;                    // stored by the direct path above
+            if (MODE != MODE1_BITS && direct) return;                       // (the sign-bit store gathers across the lanes: all stay)
             unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
             const int mclip = prow < hlim ? (int)wlim - (int)(16u * wx) : 0;   // (edge only) pixels of my window inside the cell
             if (MODE == MODE1_BITS) {
@@ -427,7 +447,8 @@ void win1_kernel(const RenderArgs A)
                     return (nz * 0x01020408u) >> 24;
                 };
                 const uint32_t bits16 = (b4(p0) & 15u) | ((b4(p1) & 15u) << 4) | ((b4(p2) & 15u) << 8) | ((b4(p3) & 15u) << 12);
-                if (prow < hlim && bits_ok) *reinterpret_cast<uint16_t *>(out_band + (size_t)prow * row_bytes + 2u * wx) = (uint16_t)bits16;
+                if (WLOG == 4) band_bits[it] = bits16;                      // (a 256-pixel strip: the whole band leaves at once, below)
+                else w1_store_bits<WLOG>(out_band + (size_t)prow * row_bytes, wx, bits16, prow < hlim && !direct);
             } else if (MODE == MODE1_MASK) {
                 auto m4 = [](uint32_t x) -> uint32_t {
                     const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
@@ -482,6 +503,24 @@ void win1_kernel(const RenderArgs A)
         } else {
 #pragma clang loop unroll(disable)
             for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) window_pass(it, std::true_type{});
+        }
+        if (MODE == MODE1_BITS && WLOG == 4) {
+            // The band's sign bits are 16 rows x 32 bytes = 512 CONTIGUOUS bytes of the strip's bit plane: through LDS (E has
+            // been read) they leave as 32 lanes x 16 bytes — four whole 128-byte lines in one store instruction.  (A row the
+            // direct path stored keeps its bits: its two lanes skip.)
+            c4_wave_lds_sync();
+            uint16_t *stage = reinterpret_cast<uint16_t *>(s_E);            // [16 rows][16 windows] u16
+#pragma unroll
+            for (uint32_t it = 0; it < (W1_ROWS * NWIN) / 64u; ++it) {
+                const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
+                stage[prow * 16u + wx] = (uint16_t)band_bits[it];
+            }
+            c4_wave_lds_sync();
+            const uint32_t row = lane >> 1;
+            if (lane < 32u && row < hlim && !((ovf_rows >> row) & 1u)) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(s_E + 16u * lane);
+                __builtin_memcpy(out_band + 16u * lane, &v, 16);
+            }
         }
         c4_wave_lds_sync();                        // E is re-initialised by the next band
     }
