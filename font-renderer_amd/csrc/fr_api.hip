@@ -298,8 +298,9 @@ static uint32_t glyph_ray_bound(const int16_t *points_xy, const uint32_t *seg_p0
 // sample rows, of glyphs with <= 384 segments and <= 512 root records the vertex rule cannot discard: in strips of
 // 64 / 128 / 256 pixels chosen from the job's own width (a 47 x 45 image does not pay for 256 columns) and bands of
 // 64 sample rows, the last strip and band clipped at the cell's border.  Everything else takes the general
-// render_kernel.  -> 0 (general) or 1 + 3 (wlog - 2) + record class (0: <= 128 slots and <= 16 crossings per ray
-// estimated, 1: <= 256 slots, 2: <= 512).
+// render_kernel.  -> 0 (general) or 1 + 4 (wlog - 2) + record class (0: <= 128 slots and <= 16 crossings per ray
+// estimated, 1: <= 256 slots, 2: <= 512 (<= 384 segments), 3: <= 1024 (<= 768 segments: two workgroups per CU)).
+enum { FAST_RC = 4, FAST_CLASSES = 3 * FAST_RC };     // record classes (128 / 256 / 512 / 1024 slots) x strip widths (64 / 128 / 256)
 struct FastRule {
     int ns = 0;             // samples per axis on the fast kernels (0: this plan has no fast kernel)
     uint32_t wlog_max = 0;  // widest strip the context allows (option "strip_px")
@@ -317,26 +318,27 @@ static FastRule fast_rule(const fr_ctx *ctx, const fr_raster_params *params)
 static int fast_class(const FastRule &R, uint32_t w, uint32_t h, uint32_t nsg, uint32_t root_bound, uint32_t ray_bound)
 {
     if (!R.ns || w == 0 || h == 0 || (uint64_t)h * (uint32_t)R.ns > 2048u) return 0;     // (12-bit sample-row fields)
-    if (nsg > fr::cov4_max_segments() || root_bound > 512u) return 0;
+    if (nsg > fr::cov4_max_segments() || root_bound > 1024u) return 0;
     const uint32_t wl = std::min(w <= 64u ? 2u : (w <= 128u ? 3u : 4u), R.wlog_max);
-    const int rc = (nsg <= 256u && root_bound <= 128u && ray_bound <= 16u) ? 0 : ((nsg <= 256u && root_bound <= 256u) ? 1 : 2);
-    return 1 + 3 * (int)(wl - 2u) + rc;
+    const int rc = (nsg <= 256u && root_bound <= 128u && ray_bound <= 16u) ? 0 : ((nsg <= 256u && root_bound <= 256u) ? 1 :
+                   ((nsg <= 384u && root_bound <= 512u) ? 2 : 3));
+    return 1 + FAST_RC * (int)(wl - 2u) + rc;
 }
 // classes of fewer than FAST_PART_MIN jobs move up into the next class that has jobs: same strip width and more record
 // slots first, then wider strips with at least as many record slots (class c = 3 (wlog - 2) + record class; cls[j] = c + 1)
 enum { FAST_PART_MIN = 64 };
-static void merge_small_classes(uint32_t counts[9], uint8_t *cls, uint32_t n_jobs)
+static void merge_small_classes(uint32_t counts[FAST_CLASSES], uint8_t *cls, uint32_t n_jobs)
 {
-    int remap[9];
+    int remap[FAST_CLASSES];
     bool any = false;
-    for (int c = 0; c < 9; ++c) {
+    for (int c = 0; c < FAST_CLASSES; ++c) {
         remap[c] = c;
         if (counts[c] == 0 || counts[c] >= (uint32_t)FAST_PART_MIN) continue;
-        const int w = c / 3, r = c % 3;
+        const int w = c / FAST_RC, r = c % FAST_RC;
         int target = -1;
         for (int w2 = w; w2 < 3 && target < 0; ++w2)
-            for (int r2 = (w2 == w ? r + 1 : r); r2 < 3; ++r2)
-                if (counts[3 * w2 + r2]) { target = 3 * w2 + r2; break; }
+            for (int r2 = (w2 == w ? r + 1 : r); r2 < FAST_RC; ++r2)
+                if (counts[FAST_RC * w2 + r2]) { target = FAST_RC * w2 + r2; break; }
         if (target < 0) continue;
         counts[target] += counts[c];          // (the target may be small itself: it is looked at later in this loop)
         counts[c] = 0;
@@ -344,7 +346,7 @@ static void merge_small_classes(uint32_t counts[9], uint8_t *cls, uint32_t n_job
         any = true;
     }
     if (!any) return;
-    for (int c = 0; c < 9; ++c) {             // chains: a -> b -> c
+    for (int c = 0; c < FAST_CLASSES; ++c) {             // chains: a -> b -> c
         int t = remap[c];
         while (remap[t] != t) t = remap[t];
         remap[c] = t;
@@ -354,17 +356,17 @@ static void merge_small_classes(uint32_t counts[9], uint8_t *cls, uint32_t n_job
 }
 
 // the fast jobs of `order` (already grouped by class, `counts[c]` jobs of class c + 1) -> the plan's launches
-static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[9], int ns)
+static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[FAST_CLASSES], int ns)
 {
     p->parts.clear();
     p->fast_ns = ns;
     if (ns <= 0) return;                                              // (no fast kernel in this plan)
     const uint32_t prb = ns == 1 ? 16u : 64u / (uint32_t)ns;          // pixel rows of a band
     uint32_t first = 0;
-    for (int c = 0; c < 9; ++c) {
+    for (int c = 0; c < FAST_CLASSES; ++c) {
         if (!counts[c]) continue;
         fr_plan::Part pt{};
-        pt.first = first; pt.cnt = counts[c]; pt.wlog = 2u + (uint32_t)(c / 3); pt.rec_cap = 128u << (c % 3);
+        pt.first = first; pt.cnt = counts[c]; pt.wlog = 2u + (uint32_t)(c / FAST_RC); pt.rec_cap = 128u << (c % FAST_RC);
         const uint32_t sw = 16u << pt.wlog;
         for (uint32_t q = first; q < first + counts[c]; ++q) {
             pt.bands = std::max(pt.bands, (sorted_jobs[q].h + prb - 1u) / prb);
@@ -559,7 +561,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     // by class — one launch per class that occurs.
     std::vector<uint32_t> order(n_jobs);
     uint32_t n_fast = 0;
-    uint32_t counts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t counts[FAST_CLASSES] = {};
     const FastRule rule = fast_rule(ctx, params);
     {
         std::vector<uint8_t> cls(n_jobs);
@@ -574,8 +576,8 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         // that exists — wider strips and / or more record slots render the same bytes (the stores are clipped, spare
         // record slots stay empty), only a little less efficiently.
         merge_small_classes(counts, cls.data(), n_jobs);
-        uint32_t at[10], run = 0;
-        for (int c = 0; c < 9; ++c) { at[c + 1] = run; run += counts[c]; }
+        uint32_t at[FAST_CLASSES + 1], run = 0;
+        for (int c = 0; c < FAST_CLASSES; ++c) { at[c + 1] = run; run += counts[c]; }
         at[0] = run;                                                      // the general kernel's jobs go last
         for (uint32_t j = 0; j < n_jobs; ++j) order[at[cls[j]]++] = j;
     }
@@ -1048,7 +1050,7 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
         const int cls = fast_class(rule, w, h, ns, glyph_root_bound(points_xy, seg_p0.data(), 0, ns),
                                    glyph_ray_bound(points_xy, seg_p0.data(), 0, ns, ev));
         if (cls && mode != FR_SDF_U8) {            // (one SDF image: the sign comes as a byte from the general kernel, no bit plane)
-            uint32_t counts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t counts[FAST_CLASSES] = {};
             counts[cls - 1] = 1;
             pl.n_fast = 1;
             make_parts(&pl, &jb, counts, rule.ns);

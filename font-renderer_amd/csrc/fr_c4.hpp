@@ -30,8 +30,9 @@ constexpr uint32_t c4_lstride(int cap) { return (uint32_t)cap + 4u; }
 // workgroups fit a CU if the kernel stays within 80 VGPRs: measured 0.0754 -> 0.0643 ms on configs[3]'s shard (128^2
 // cells), 0.343 -> 0.291 ms on 256^2 cells of 32 segments — and nothing at five (an odd number of waves per SIMD: DESIGN.md
 // section 4.0).  The instances that keep 32 crossings or more records are bound to four (three) by their LDS.
-constexpr int c4_occ(int cap, int wlog, int rpl) { return (cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC; }
-constexpr int w1_occ(int rpl, int wlog) { return (rpl == 2) ? FR_W1_OCC_SMALL : FR_C4_OCC; }
+// (the 1024-record instances: 77 KB of LDS, two workgroups per CU — the register budget of two waves per SIMD)
+constexpr int c4_occ(int cap, int wlog, int rpl) { return rpl >= 16 ? 2 : ((cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC); }
+constexpr int w1_occ(int rpl, int wlog) { return rpl >= 16 ? 2 : ((rpl == 2) ? FR_W1_OCC_SMALL : FR_C4_OCC); }
 // 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
 template <uint32_t LSTRIDE>
 __device__ __forceinline__ uint4 c4_ld16(const uint16_t *p)
@@ -273,7 +274,8 @@ __device__ __forceinline__ uint32_t c4_setup(const RenderArgs &A, const Job &job
         return c4_setup_mid<RCAP, N, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, s_tmp, cyt);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t Hs = job.h * (uint32_t)N;
-    constexpr uint32_t CPT = (RCAP >= 512u ? 768u : 512u) / (64u * NW);     // candidates per thread (<= 384 segments where 512 records are kept, else <= 256)
+    // candidates per thread: <= 768 segments where 1024 records are kept, <= 384 where 512, else <= 256
+    constexpr uint32_t CPT = (RCAP >= 1024u ? 1536u : (RCAP >= 512u ? 768u : 512u)) / (64u * NW);
     s_wcnt = s_tmp;                                                          // (2 CPT NW counters: the scratch block has the room)
     Rec40 mine[CPT];
     unsigned long long lm[CPT], ll[CPT];

@@ -242,7 +242,12 @@ void cov4_kernel(const RenderArgs A)
                     // my records' row offsets sit side by side: one store
                     if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
                     else if constexpr (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
-                    else if constexpr (RPL == 8) *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                    else if constexpr (RPL >= 8) {
+#pragma unroll
+                    for (int q8 = 0; q8 < RPL / 8; ++q8)
+                        reinterpret_cast<uint4 *>(s_roff + (uint32_t)RPL * lane)[q8] = make_uint4(ro[8 * q8] | (ro[8 * q8 + 1] << 16), ro[8 * q8 + 2] | (ro[8 * q8 + 3] << 16),
+                                                                                                  ro[8 * q8 + 4] | (ro[8 * q8 + 5] << 16), ro[8 * q8 + 6] | (ro[8 * q8 + 7] << 16));
+                }
                 }
                 const uint32_t npairs = tot;
                 uint32_t carry = 0u;               // record index (+ 1) of the last pair walked so far
@@ -684,7 +689,7 @@ extern "C" int fr_debug_read_c4_stats(unsigned long long *out16, int reset)
 }
 #endif
 uint32_t cov4_wg_waves() { return C4_WAVES; }
-uint32_t cov4_max_segments() { return 384u; }     // (with 512 record slots; 256 for the smaller instances: fr_plan_create)
+uint32_t cov4_max_segments() { return 768u; }     // (with 1024 record slots; 384 with 512, 256 for the smaller instances: fr_plan_create)
 
 template <int WLOG, int RPL, int NS>
 static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
@@ -693,7 +698,8 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
     // 1 row in 100 000): their instance keeps 16 per row in registers — half the list to initialise, pull and sort, 5 %
     // faster — and the rare fuller row takes the direct sum like any over-full row
     const uint32_t kmax = (RPL == 2 && a.kmax > 16u) ? 16u : a.kmax;
-    const int cap = kmax <= 8 ? 8 : (kmax <= 16 ? 16 : 32);
+    // (the 1024-record instance — glyphs of 385 .. 768 segments, rare — exists with 32 kept crossings only)
+    const int cap = RPL >= 16 ? 32 : (kmax <= 8 ? 8 : (kmax <= 16 ? 16 : 32));
     // the instance as rocprofv3 names it
     if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, %d, %d, %d>", WLOG, cap, RPL, NS);
     if (!grid.x) return hipSuccess;                // (name only)
@@ -706,8 +712,10 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
         hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
         return hipGetLastError();
     };
-    if (cap == 8) return launch(cov4_kernel<WLOG, 8, RPL, NS>);
-    if (cap == 16) return launch(cov4_kernel<WLOG, 16, RPL, NS>);
+    if constexpr (RPL < 16) {
+        if (cap == 8) return launch(cov4_kernel<WLOG, 8, RPL, NS>);
+        if (cap == 16) return launch(cov4_kernel<WLOG, 16, RPL, NS>);
+    }
     return launch(cov4_kernel<WLOG, 32, RPL, NS>);
 }
 
@@ -716,6 +724,7 @@ static hipError_t cov4_launch_rpl(const RenderArgs &a, uint32_t rec_cap, dim3 gr
 {
     if (rec_cap <= 128u) return cov4_launch_cap<WLOG, 2, NS>(a, grid, stream, name, name_cap);
     if (rec_cap <= 256u) return cov4_launch_cap<WLOG, 4, NS>(a, grid, stream, name, name_cap);
+    if (rec_cap > 512u) return cov4_launch_cap<WLOG, 16, NS>(a, grid, stream, name, name_cap);
     return cov4_launch_cap<WLOG, 8, NS>(a, grid, stream, name, name_cap);
 }
 

@@ -205,7 +205,12 @@ void win1_kernel(const RenderArgs A)
                 }
                 if (few) *reinterpret_cast<uint32_t *>(s_roff + 2u * lane) = ro[0] | (ro[1] << 16);
                 else if constexpr (RPL == 4) *reinterpret_cast<uint2 *>(s_roff + 4u * lane) = make_uint2(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16));
-                else if constexpr (RPL == 8) *reinterpret_cast<uint4 *>(s_roff + 8u * lane) = make_uint4(ro[0] | (ro[1] << 16), ro[2] | (ro[3] << 16), ro[RPL - 4] | (ro[RPL - 3] << 16), ro[RPL - 2] | (ro[RPL - 1] << 16));
+                else if constexpr (RPL >= 8) {
+#pragma unroll
+                    for (int q8 = 0; q8 < RPL / 8; ++q8)
+                        reinterpret_cast<uint4 *>(s_roff + (uint32_t)RPL * lane)[q8] = make_uint4(ro[8 * q8] | (ro[8 * q8 + 1] << 16), ro[8 * q8 + 2] | (ro[8 * q8 + 3] << 16),
+                                                                                                  ro[8 * q8 + 4] | (ro[8 * q8 + 5] << 16), ro[8 * q8 + 6] | (ro[8 * q8 + 7] << 16));
+                }
                 c4_wave_lds_sync();
                 const uint32_t npairs = tot;
                 uint32_t k_cur = c4_wave_incl_max((uint32_t)s_pairs[lane]);
@@ -553,6 +558,7 @@ static hipError_t win1_launch_rpl(const RenderArgs &a, int mode, uint32_t rec_ca
 {
     if (rec_cap <= 128u) return win1_launch_mode<WLOG, 2>(a, mode, grid, stream, name, name_cap);
     if (rec_cap <= 256u) return win1_launch_mode<WLOG, 4>(a, mode, grid, stream, name, name_cap);
+    if (rec_cap > 512u) return win1_launch_mode<WLOG, 16>(a, mode, grid, stream, name, name_cap);
     return win1_launch_mode<WLOG, 8>(a, mode, grid, stream, name, name_cap);
 }
 

@@ -85,12 +85,12 @@ def test_coverage_synthetic(ctx, oracle, segs, cell):
 
 
 def test_mixed_glyph_sizes_in_one_plan(ctx, oracle):
-    """The fused / staged decision is per JOB: one plan holding glyphs of 24, 128, 129, 200 and 520
-    segments (the last one needs three 256-record chunks) renders every cell like the oracle; the small
-    glyphs keep taking the in-kernel record build whatever else is in the set."""
+    """The kernel decision is per JOB: one plan holding glyphs of 24, 128, 129, 200, 520 and 800 segments (520: the
+    1024-record instances of the fast kernels; 800: the general kernel, four 256-record chunks) renders every cell like the
+    oracle; the small glyphs keep taking the in-kernel record build whatever else is in the set."""
     parts = [synth_glyphset(2, 24, first_index=11), synth_glyphset(2, 128, first_index=12),
              synth_glyphset(1, 129, first_index=13), synth_glyphset(2, 200, first_index=14),
-             synth_glyphset(1, 520, first_index=15), synth_glyphset(2, 64, first_index=16)]
+             synth_glyphset(1, 520, first_index=15), synth_glyphset(2, 64, first_index=16), synth_glyphset(1, 800, first_index=17)]
     gl = [p.glyph(i) for p in parts for i in range(len(p))]
     gs = GlyphSet(gl)
     for cell, n in ((128, 4), (256, 4), (96, 2), (80, 1)):
@@ -98,8 +98,8 @@ def test_mixed_glyph_sizes_in_one_plan(ctx, oracle):
         got, ref = _batch_both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, atlas_shape(len(gs), cell, 5), n, True, threads=16)
         assert np.array_equal(got, ref), (cell, n)
         if cell in (128, 256):
-            # this plan holds all four kinds of job (<= 128 / 256 / 512 candidate roots: cov4_kernel with 2 / 4 / 8 records per
-            # lane; 520 segments: the general kernel, forked onto the context's second stream) — the same bytes in one stream
+            # this plan holds all five kinds of job (<= 128 / 256 / 512 / 1024 candidate roots: cov4_kernel with 2 / 4 / 8 / 16
+            # records per lane; 800 segments: the general kernel, forked onto the context's second stream) — the same bytes in one stream
             st = fr.Plan(fr.DeviceGlyphSet(ctx, gs), jobs, fr.FR_COVERAGE_U8, n, fr.FR_SAMPLE_CENTER).stats()
             assert st["jobs_cov4"] == len(gs) - 1 and st["jobs_general"] == 1, st
             assert np.array_equal(_render_opt(ctx, gs, jobs, atlas_shape(len(gs), cell, 5), n, True, overlap=0), ref)

@@ -163,7 +163,7 @@ def test_strip_px_option_bounds_the_fast_strips(ctx, oracle, ascii_set):
 def test_sdf_on_ragged_cells_and_mixed_plans(ctx, oracle, ascii_set):
     """FR_SDF_U8 with the sign travelling as one bit per pixel (win1_kernel's sign-bit mode -> sdf_kernel, which is then the
     only writer of the output): renderGlyph-sized images (ragged, unaligned) of real glyphs, and a plan that mixes fast
-    jobs (bit planes) with a 520-segment glyph (general kernel: the sign as a byte in the output), against the CPU twin;
+    jobs (bit planes) with an 800-segment glyph (general kernel: the sign as a byte in the output), against the CPU twin;
     the bytes around every cell stay untouched"""
     gs = ascii_set.gs
     jobs, H = glyph_dims_jobs(gs, 90, ascii_set.g_upm, 1531, n_glyphs=120)
@@ -173,7 +173,7 @@ def test_sdf_on_ragged_cells_and_mixed_plans(ctx, oracle, ascii_set):
                                ["fr::win1_kernel<", ", 3, ", "fr::sdf_kernel"])
         assert np.array_equal(got, ref), (center, desc)
     dgs.close()
-    parts = [synth_glyphset(3, 40, first_index=21), synth_glyphset(1, 520, first_index=22), synth_glyphset(2, 100, first_index=23)]
+    parts = [synth_glyphset(3, 40, first_index=21), synth_glyphset(1, 800, first_index=22), synth_glyphset(2, 100, first_index=23)]
     gs = GlyphSet([p.glyph(i) for p in parts for i in range(len(p))])
     jobs = cell_jobs(gs, 200, 180, 2048, 3)
     jobs["w"] = [200, 131, 64, 200, 33, 190]
@@ -242,3 +242,18 @@ def test_full_size_properties_config5_shard_of_the_real_font(ctx, oracle):
         assert np.array_equal(host[y:y + cell, x:x + cell], ref), k
     dgs.close()
     assert 0.0 < float((first == 0).float().mean()) < 1.0 and 0.0 < float((first == 255).float().mean()) < 1.0
+
+
+@pytest.mark.parametrize("segs", [400, 512, 700])
+def test_glyphs_of_385_to_768_segments_take_the_1024_record_instances(ctx, oracle, segs):
+    """glyphs the round-2 library left to the general kernel (more than 384 segments): cov4_kernel / win1_kernel with 16
+    records per lane (1024 record slots, two workgroups per CU), ragged cells, every mode == the oracle"""
+    gs = GlyphSet([synth_glyphset(2, segs, first_index=3000 + segs).glyph(i) for i in range(2)] + [stroke_glyphset(1, segs, first_index=77).glyph(0)])
+    jobs = cell_jobs(gs, 256, 240, 2048, 3)
+    jobs["w"] = [256, 200, 77]
+    jobs["h"] = [256, 131, 250]
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    for mode, omode, n, center in [ONE[1], ONE[0], (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 4, True), (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 2, False), (fr.FR_SDF_U8, O.SDF_U8, 1, True)]:
+        got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, atlas_shape(len(gs), 256, 3), n, center, dgs, 0, [", 16" if n == 1 else ", 16, "])
+        assert np.array_equal(got, ref), (segs, mode, n, desc)
+    dgs.close()
