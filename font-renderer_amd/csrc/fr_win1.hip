@@ -193,7 +193,9 @@ void win1_kernel(const RenderArgs A)
                 span >>= 1;
             }
             if (tot) {
-                if (PCAP >= 512u || lane < PCAP / 8u) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (uint32_t q = 0; q < (PCAP / 8u + 63u) / 64u; ++q)
+                    if (PCAP / 8u % 64u == 0u || lane + 64u * q < PCAP / 8u) reinterpret_cast<uint4 *>(s_pairs)[lane + 64u * q] = make_uint4(0, 0, 0, 0);
                 c4_wave_lds_sync();
                 uint32_t off = incl - csum;
                 uint32_t ro[RPL];
