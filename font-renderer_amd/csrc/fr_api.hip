@@ -21,8 +21,8 @@ void launch_prepare(const int16_t *, const uint32_t *, const uint32_t *, const u
                     uint32_t *, hipStream_t);
 hipError_t launch_render(const RenderArgs &, int mode, int n, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
 uint32_t render_wg_waves();
-hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, int ns, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0, bool wpj = false);
-hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0, bool wpj = false);
+hipError_t launch_cov4(const RenderArgs &, uint32_t rec_cap, int ns, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
+hipError_t launch_win1(const RenderArgs &, int mode1, uint32_t rec_cap, hipStream_t, bool launch = true, char *name = nullptr, size_t name_cap = 0);
 uint32_t cov4_wg_waves();
 uint32_t cov4_max_segments();
 hipError_t launch_sdf(const RenderArgs &, uint32_t, uint32_t, uint32_t max_seg, int cull, hipStream_t);
@@ -79,7 +79,6 @@ struct fr_ctx {
     uint32_t cov4 = 1;           // 16-sample coverage of uniform cells takes cov4_kernel (fr_cov4.hip) where it fits
     uint32_t zero_copy = 0;      // fr_render_glyph: render small glyphs from / into pinned host memory directly (measured: no faster than two small copies; off)
     uint32_t sdf_cull = 1;       // FR_SDF_U8: drop segments that cannot change a tile / a pixel (exact; 0 = look at all, for tests)
-    uint32_t wpj = 1;            // small cells of small glyphs: a wave per job (0: a workgroup per job, as every other cell)
     uint32_t overlap = 1;        // a plan's smaller launches run beside its largest one on a second stream: 0 never, 1 plans of >= 32 Mpixel, 2 always
     hipStream_t aux = nullptr;   // that second stream and the fork / join events, created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -117,7 +116,7 @@ struct fr_plan {
     // into `parts` — one launch each, by strip width (64 / 128 / 256 pixels, from the job's own width) and by the record
     // slots the glyph needs (128 / 256 / 512); the general kernel renders the other n_jobs - n_fast
     uint32_t n_fast = 0;
-    struct Part { uint32_t first, cnt, wlog, rec_cap, bands, strips; uint64_t pixels; bool wpj; };
+    struct Part { uint32_t first, cnt, wlog, rec_cap, bands, strips; uint64_t pixels; };
     std::vector<Part> parts;
     int fast_ns = 0;                   // samples per axis of the fast kernels' jobs (4 / 2: cov4_kernel, 1: win1_kernel)
     uint32_t gen_bands = 0, gen_strips = 0;
@@ -203,7 +202,6 @@ int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "lds_pad")) { ctx->lds_pad = (uint32_t)value; return FR_OK; }
     if (!strcmp(key, "cov4")) { ctx->cov4 = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "sdf_cull")) { ctx->sdf_cull = value ? 1u : 0u; return FR_OK; }
-    if (!strcmp(key, "wpj")) { ctx->wpj = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "overlap")) {
         if (value < 0 || value > 2) return fail(FR_E_INVALID, "overlap must be 0 (never), 1 (plans of >= 32 Mpixel) or 2 (always)");
         ctx->overlap = (uint32_t)value;
@@ -302,13 +300,10 @@ static uint32_t glyph_ray_bound(const int16_t *points_xy, const uint32_t *seg_p0
 // 64 sample rows, the last strip and band clipped at the cell's border.  Everything else takes the general
 // render_kernel.  -> 0 (general) or 1 + 4 (wlog - 2) + record class (0: <= 128 slots and <= 16 crossings per ray
 // estimated, 1: <= 256 slots, 2: <= 512 (<= 384 segments), 3: <= 1024 (<= 768 segments: two workgroups per CU)).
-// record classes (128 / 256 / 512 / 1024 slots) x strip widths (64 / 128 / 256), then the two wave-per-job classes (64- / 128-pixel
-// strips: small cells of small glyphs, four cells per workgroup)
-enum { FAST_RC = 4, FAST_CLASSES = 3 * FAST_RC, FAST_ALL = FAST_CLASSES + 2 };
+enum { FAST_RC = 4, FAST_CLASSES = 3 * FAST_RC };     // record classes (128 / 256 / 512 / 1024 slots) x strip widths (64 / 128 / 256)
 struct FastRule {
     int ns = 0;             // samples per axis on the fast kernels (0: this plan has no fast kernel)
     uint32_t wlog_max = 0;  // widest strip the context allows (option "strip_px")
-    bool wpj = true;        // small cells of small glyphs take the wave-per-job instances (option "wpj")
 };
 static FastRule fast_rule(const fr_ctx *ctx, const fr_raster_params *params)
 {
@@ -318,7 +313,6 @@ static FastRule fast_rule(const fr_ctx *ctx, const fr_raster_params *params)
                      (params->mode == FR_COVERAGE_U8 && n == 1) || params->mode == FR_SDF_U8;   // (SDF: its sign pass)
     r.wlog_max = ctx->strip_px >= 256u ? 4u : (ctx->strip_px >= 128u ? 3u : (ctx->strip_px >= 64u ? 2u : 0u));
     if (ctx->cov4 && r.wlog_max) r.ns = one ? 1 : ((params->mode == FR_COVERAGE_U8 && (n == 4 || n == 2)) ? n : 0);
-    r.wpj = ctx->wpj != 0;
     return r;
 }
 static int fast_class(const FastRule &R, uint32_t w, uint32_t h, uint32_t nsg, uint32_t root_bound, uint32_t ray_bound)
@@ -328,29 +322,15 @@ static int fast_class(const FastRule &R, uint32_t w, uint32_t h, uint32_t nsg, u
     const uint32_t wl = std::min(w <= 64u ? 2u : (w <= 128u ? 3u : 4u), R.wlog_max);
     const int rc = (nsg <= 256u && root_bound <= 128u && ray_bound <= 16u) ? 0 : ((nsg <= 256u && root_bound <= 256u) ? 1 :
                    ((nsg <= 384u && root_bound <= 512u) ? 2 : 3));
-    // wave per job: one strip of 64 / 128 pixels, at most four bands (64 sample-row bands: 64 rows at one or 4 x 4 samples —
-    // win1's bands are 16 rows —, 128 at 2 x 2), a glyph of <= 32 segments (one candidate root per lane of ONE wave) with few
-    // crossings per ray: the images of text sizes
-    const uint32_t max_h_wpj = R.ns == 2 ? 128u : 64u;
-    if (R.wpj && rc == 0 && wl <= 3u && w <= (16u << wl) && h <= max_h_wpj && nsg <= 32u) return 1 + FAST_CLASSES + (int)(wl - 2u);
     return 1 + FAST_RC * (int)(wl - 2u) + rc;
 }
 // classes of fewer than FAST_PART_MIN jobs move up into the next class that has jobs: same strip width and more record
 // slots first, then wider strips with at least as many record slots (class c = 3 (wlog - 2) + record class; cls[j] = c + 1)
 enum { FAST_PART_MIN = 64 };
-static void merge_small_classes(uint32_t counts[FAST_ALL], uint8_t *cls, uint32_t n_jobs)
+static void merge_small_classes(uint32_t counts[FAST_CLASSES], uint8_t *cls, uint32_t n_jobs)
 {
-    int remap[FAST_ALL];
+    int remap[FAST_CLASSES];
     bool any = false;
-    for (int c = FAST_CLASSES; c < FAST_ALL; ++c) {       // a small wave-per-job class joins the workgroup-per-job class of its strip width
-        remap[c] = c;
-        if (counts[c] == 0 || counts[c] >= (uint32_t)FAST_PART_MIN) continue;
-        const int target = FAST_RC * (c - FAST_CLASSES);
-        counts[target] += counts[c];
-        counts[c] = 0;
-        remap[c] = target;
-        any = true;
-    }
     for (int c = 0; c < FAST_CLASSES; ++c) {
         remap[c] = c;
         if (counts[c] == 0 || counts[c] >= (uint32_t)FAST_PART_MIN) continue;
@@ -366,7 +346,7 @@ static void merge_small_classes(uint32_t counts[FAST_ALL], uint8_t *cls, uint32_
         any = true;
     }
     if (!any) return;
-    for (int c = 0; c < FAST_ALL; ++c) {                 // chains: a -> b -> c
+    for (int c = 0; c < FAST_CLASSES; ++c) {             // chains: a -> b -> c
         int t = remap[c];
         while (remap[t] != t) t = remap[t];
         remap[c] = t;
@@ -376,20 +356,17 @@ static void merge_small_classes(uint32_t counts[FAST_ALL], uint8_t *cls, uint32_
 }
 
 // the fast jobs of `order` (already grouped by class, `counts[c]` jobs of class c + 1) -> the plan's launches
-static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[FAST_ALL], int ns)
+static void make_parts(fr_plan *p, const fr_job *sorted_jobs, const uint32_t counts[FAST_CLASSES], int ns)
 {
     p->parts.clear();
     p->fast_ns = ns;
     if (ns <= 0) return;                                              // (no fast kernel in this plan)
     const uint32_t prb = ns == 1 ? 16u : 64u / (uint32_t)ns;          // pixel rows of a band
     uint32_t first = 0;
-    for (int c = 0; c < FAST_ALL; ++c) {
+    for (int c = 0; c < FAST_CLASSES; ++c) {
         if (!counts[c]) continue;
         fr_plan::Part pt{};
-        pt.wpj = c >= FAST_CLASSES;
-        pt.first = first; pt.cnt = counts[c];
-        pt.wlog = pt.wpj ? 2u + (uint32_t)(c - FAST_CLASSES) : 2u + (uint32_t)(c / FAST_RC);
-        pt.rec_cap = pt.wpj ? 64u : 128u << (c % FAST_RC);
+        pt.first = first; pt.cnt = counts[c]; pt.wlog = 2u + (uint32_t)(c / FAST_RC); pt.rec_cap = 128u << (c % FAST_RC);
         const uint32_t sw = 16u << pt.wlog;
         for (uint32_t q = first; q < first + counts[c]; ++q) {
             pt.bands = std::max(pt.bands, (sorted_jobs[q].h + prb - 1u) / prb);
@@ -584,7 +561,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
     // by class — one launch per class that occurs.
     std::vector<uint32_t> order(n_jobs);
     uint32_t n_fast = 0;
-    uint32_t counts[FAST_ALL] = {};
+    uint32_t counts[FAST_CLASSES] = {};
     const FastRule rule = fast_rule(ctx, params);
     {
         std::vector<uint8_t> cls(n_jobs);
@@ -599,8 +576,8 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
         // that exists — wider strips and / or more record slots render the same bytes (the stores are clipped, spare
         // record slots stay empty), only a little less efficiently.
         merge_small_classes(counts, cls.data(), n_jobs);
-        uint32_t at[FAST_ALL + 1], run = 0;
-        for (int c = 0; c < FAST_ALL; ++c) { at[c + 1] = run; run += counts[c]; }
+        uint32_t at[FAST_CLASSES + 1], run = 0;
+        for (int c = 0; c < FAST_CLASSES; ++c) { at[c + 1] = run; run += counts[c]; }
         at[0] = run;                                                      // the general kernel's jobs go last
         for (uint32_t j = 0; j < n_jobs; ++j) order[at[cls[j]]++] = j;
     }
@@ -712,8 +689,8 @@ int fr_plan_describe(const fr_plan *plan, char *buf, size_t cap)
     for (const auto &pt : plan->parts) {
         a.strip_w = 16u << pt.wlog;
         name[0] = 0;
-        if (plan->fast_ns > 1) (void)fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, nullptr, false, name, sizeof name, pt.wpj);
-        else (void)fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : (pm == FR_SDF_U8 ? 3 : 2)), pt.rec_cap, nullptr, false, name, sizeof name, pt.wpj);
+        if (plan->fast_ns > 1) (void)fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, nullptr, false, name, sizeof name);
+        else (void)fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : (pm == FR_SDF_U8 ? 3 : 2)), pt.rec_cap, nullptr, false, name, sizeof name);
         add(name, pt.cnt);
     }
     if (plan->n_jobs > plan->n_fast) {
@@ -819,16 +796,16 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         split_bands(fr::cov4_wg_waves(), pt.cnt, pt.bands, pt.strips);
         const int pm = plan->params.mode;
         hipStream_t pst = (forked && i != big) ? ctx->aux : ctx->stream;
-        if (plan->fast_ns > 1) HIP_TRY(fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, pst, true, nullptr, 0, pt.wpj));
+        if (plan->fast_ns > 1) HIP_TRY(fr::launch_cov4(a, pt.rec_cap, plan->fast_ns, pst));
         else if (sdf && plan->d_bits) {
             // the sign pass of FR_SDF_U8: one bit per pixel into the job's own bit plane
             void *const keep = a.out;
             a.out = plan->d_bits; a.job_bits = plan->d_job_bits + pt.first;
-            const hipError_t le = fr::launch_win1(a, 3, pt.rec_cap, pst, true, nullptr, 0, pt.wpj);
+            const hipError_t le = fr::launch_win1(a, 3, pt.rec_cap, pst);
             a.out = keep; a.job_bits = nullptr;
             HIP_TRY(le);
         }
-        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, pst, true, nullptr, 0, pt.wpj));
+        else HIP_TRY(fr::launch_win1(a, pm == FR_WINDING_I16 ? 0 : (pm == FR_GRAY_DEBUG ? 1 : 2), pt.rec_cap, pst));
     }
     return FR_OK;
     };
@@ -1068,13 +1045,12 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
     {
         // the same per-job rule as fr_plan_create: the image takes win1_kernel (64- / 128- / 256-pixel strips by its
         // own width) unless the glyph is too large for it
-        FastRule rule = fast_rule(ctx, &prm);
-        rule.wpj = false;                          // (one image: its bands side by side on the waves of one workgroup)
+        const FastRule rule = fast_rule(ctx, &prm);
         std::vector<std::pair<int32_t, int32_t>> ev;
         const int cls = fast_class(rule, w, h, ns, glyph_root_bound(points_xy, seg_p0.data(), 0, ns),
                                    glyph_ray_bound(points_xy, seg_p0.data(), 0, ns, ev));
         if (cls && mode != FR_SDF_U8) {            // (one SDF image: the sign comes as a byte from the general kernel, no bit plane)
-            uint32_t counts[FAST_ALL] = {};
+            uint32_t counts[FAST_CLASSES] = {};
             counts[cls - 1] = 1;
             pl.n_fast = 1;
             make_parts(&pl, &jb, counts, rule.ns);

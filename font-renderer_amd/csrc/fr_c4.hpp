@@ -31,8 +31,7 @@ constexpr uint32_t c4_lstride(int cap) { return (uint32_t)cap + 4u; }
 // cells), 0.343 -> 0.291 ms on 256^2 cells of 32 segments — and nothing at five (an odd number of waves per SIMD: DESIGN.md
 // section 4.0).  The instances that keep 32 crossings or more records are bound to four (three) by their LDS.
 // (the 1024-record instances: 77 KB of LDS, two workgroups per CU — the register budget of two waves per SIMD)
-// (the wave-per-job instances keep a cx table and records per WAVE: 29 - 35 KB per workgroup, four per CU)
-constexpr int c4_occ(int cap, int wlog, int rpl, bool wpj = false) { return rpl >= 16 ? 2 : ((cap <= 16 && rpl == 2 && !wpj) ? FR_C4_OCC_SMALL : FR_C4_OCC); }
+constexpr int c4_occ(int cap, int wlog, int rpl) { return rpl >= 16 ? 2 : ((cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC); }
 constexpr int w1_occ(int rpl, int wlog) { return rpl >= 16 ? 2 : ((rpl == 2) ? FR_W1_OCC_SMALL : FR_C4_OCC); }
 // 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
 template <uint32_t LSTRIDE>
@@ -259,41 +258,6 @@ __device__ __forceinline__ uint32_t c4_setup_mid(const RenderArgs &A, const Job 
     if (wave < 2u && pos < RCAP) s_rec[pos] = mine;
     __syncthreads();
     return min(n_quad + l0 + l1, RCAP);
-}
-
-// Set-up by ONE wave for its own cell (the wave-per-job instances: glyphs of <= 32 segments, one candidate root per
-// lane): the exact row range of every candidate (build_record_rows: the guess and the walk), the live records
-// compacted into the wave's own s_rec — quadratic first, linear last, as c4_setup — and the wave's own cx table.
-// No workgroup barrier: the four waves of the workgroup serve four different cells.  -> number of records (<= 64).
-template <int N, uint32_t NCOL>
-__device__ __forceinline__ uint32_t c4_setup_wave(const RenderArgs &A, const Job &job, uint32_t seg0, uint32_t nseg, int phase,
-                                                  float *s_cxp, Rec40 *s_rec, const float *cyt = nullptr)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    RowGeom geo;
-    geo.max_y = job.max_y; geo.scale = job.scale; geo.rows = job.h * (uint32_t)N; geo.n = N; geo.phase = phase; geo.cyt = cyt;
-    Rec40 mine;
-    mine.fr = 0u;
-    bool live = false;
-    if (lane < 2u * nseg) {
-        Rec r;
-        build_record_rows(A.seg_pts + 6u * (size_t)(seg0 + (lane >> 1)), lane & 1u, geo, r);
-        const uint32_t ra = __builtin_bit_cast(uint32_t, r.lo), re = __builtin_bit_cast(uint32_t, r.hi);
-        live = ra < re;
-        mine = c4_make_rec40(r, ra, re);
-    }
-    const bool linr = live && (int32_t)mine.fr < 0;
-    const unsigned long long lm = __ballot(live && !linr), ll = __ballot(linr), below = (1ull << lane) - 1ull;
-    const uint32_t n_quad = (uint32_t)__popcll(lm);
-    if ((lm >> lane) & 1ull) s_rec[(uint32_t)__popcll(lm & below)] = mine;
-    if ((ll >> lane) & 1ull) s_rec[n_quad + (uint32_t)__popcll(ll & below)] = mine;
-    // exact sample abscissae of the cell's one strip: cx(j) = (f32(min_x + x) + off(i)) / scale   (:26)
-    for (uint32_t j = lane; j < NCOL; j += 64u)
-        s_cxp[1u + j] = ((float)(job.min_x + (int32_t)(j / (uint32_t)N)) + sub_off((int)(j % (uint32_t)N), N, phase)) / job.scale;
-    if (lane == 2) s_cxp[0] = -__builtin_inff();
-    if (lane == 3) s_cxp[1u + NCOL] = __builtin_inff();
-    c4_wave_lds_sync();
-    return n_quad + (uint32_t)__popcll(ll);
 }
 
 // Set-up of a workgroup of NW waves for one cell strip: candidate roots tid, tid + 64 NW, ... (<= 256 segments; <= 384 where RCAP = 512) with the

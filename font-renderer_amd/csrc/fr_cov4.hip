@@ -90,21 +90,20 @@ __device__ unsigned long long g_c4_stats[16];
 #define C4_ABL_NODECODE 0
 #endif
 // LDS plan (bytes): cx table | records | 8 x per-wave region | per-wave counters of the record compaction
-template <int WLOG, int RPL, int NS, int CAP, bool WPJ = false>
+template <int WLOG, int RPL, int NS, int CAP>
 struct C4Lds {
     static constexpr uint32_t LSTRIDE = c4_lstride(CAP);
-    static constexpr uint32_t PCAP = WPJ ? 192u : (uint32_t)C4_PCAP;        // (record, row) pairs laid out per round
     static constexpr uint32_t NCOL = (16u << WLOG) * (uint32_t)NS;          // sample columns of a strip
     static constexpr uint32_t PRB = 64u / (uint32_t)NS;                     // pixel rows of a wave band (64 sample rows)
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;         // padded cx table
-    static constexpr uint32_t RCAP = WPJ ? 64u : 64u * RPL;                 // root records a workgroup (wave-per-job: a wave) keeps
+    static constexpr uint32_t RCAP = 64u * RPL;                             // root records a workgroup keeps
     static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
     static constexpr uint32_t EROW = (16u << WLOG) + 16u;                   // bytes per pixel row of E (one 16-B pad)
     static constexpr uint32_t E = PRB * EROW;
     // walk buffers: lists [64][LSTRIDE] u16 | markers [PCAP] u16 | cy [64] f32 | cnt [64] u32 | roff [256] i16
     static constexpr uint32_t LISTS = 64u * LSTRIDE * 2u;
     static constexpr uint32_t OFF_PAIRS = LISTS;
-    static constexpr uint32_t OFF_CY = OFF_PAIRS + PCAP * 2u;
+    static constexpr uint32_t OFF_CY = OFF_PAIRS + C4_PCAP * 2u;
     static constexpr uint32_t OFF_CNT = OFF_CY + 256u;
     static constexpr uint32_t OFF_ROFF = OFF_CNT + 256u;
     static constexpr uint32_t WALK = OFF_ROFF + RCAP * 2u;
@@ -114,9 +113,7 @@ struct C4Lds {
     static constexpr uint32_t WAVE = (WALK > E + WD ? WALK : E + WD);   // (E + an over-full row's 16-bit differences)
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
-    // wave-per-job: every wave has its own cx table, records and walk region, one after the other
-    static constexpr uint32_t PER_WAVE = CX + REC + WAVE;
-    static constexpr uint32_t TOTAL = WPJ ? C4_WAVES * PER_WAVE : OFF_WCNT + 64u;
+    static constexpr uint32_t TOTAL = OFF_WCNT + 64u;
 };
 
 // finished pixels of one 16-pixel window, clipped to the cell: the first m of the 16 bytes (m <= 0: none)
@@ -136,16 +133,11 @@ __device__ __forceinline__ void c4_store_clip(unsigned char *dst, uint4 v, int m
 // fuller rows take the direct sum over the glyph's records.  RPL: root records per lane, 2, 4 or 8 — a workgroup
 // keeps up to 64 RPL records in LDS (128 / 256: four workgroups per CU; 512: three).  NS: samples per pixel axis,
 // 4 (16 samples per pixel) or 2 (4): a wave band is 64 sample rows = 64 / NS pixel rows.
-// WPJ ("wave per job"): small cells of small glyphs — one strip wide, at most 4 bands tall, <= 32 segments: text sizes —
-// get a WAVE each instead of a workgroup: the four waves of a workgroup serve four different cells, each with its own cx
-// table, records and set-up, walking its cell's bands one after the other; no workgroup barrier anywhere.  (A workgroup
-// per such cell leaves one to three of its waves idle and pays the set-up's latency chain per cell.)
-template <int WLOG, int CAP, int RPL, int NS, bool WPJ = false>
-__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP, WLOG, RPL, WPJ), c4_occ(CAP, WLOG, RPL, WPJ))))
+template <int WLOG, int CAP, int RPL, int NS>
+__global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(c4_occ(CAP, WLOG, RPL), c4_occ(CAP, WLOG, RPL))))
 void cov4_kernel(const RenderArgs A)
 {
-    using L = C4Lds<WLOG, RPL, NS, CAP, WPJ>;
-    static_assert(!WPJ || RPL == 2, "wave-per-job instances keep two records per lane");
+    using L = C4Lds<WLOG, RPL, NS, CAP>;
     constexpr uint32_t LSTRIDE = L::LSTRIDE;
     static_assert(NS == 4 || NS == 2, "samples per axis");
     constexpr uint32_t RCAP = L::RCAP;
@@ -159,32 +151,26 @@ void cov4_kernel(const RenderArgs A)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
-    if (!WPJ && A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
-    if (!WPJ && A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
-    const uint32_t jidx = WPJ ? bid * NW + wave : bid;                      // (wave-per-job: one strip, all bands, my own cell)
-    if (WPJ && jidx >= A.n_jobs) return;
+    if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
+    if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
+    const uint32_t jidx = bid;
     C4_ABL_LAUNCH_ONLY();
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * SW;
-    const uint32_t band_first = WPJ ? 0u : bgrp * A.bands_per_wg;
-    if (band_first * PRB >= job.h || x0s >= job.w) return;                  // workgroup-uniform (wave-per-job: my wave's own)
-    const uint32_t band_end = WPJ ? (job.h + PRB - 1u) / PRB : min(band_first + A.bands_per_wg, (job.h + PRB - 1u) / PRB);
+    const uint32_t band_first = bgrp * A.bands_per_wg;
+    if (band_first * PRB >= job.h || x0s >= job.w) return;                  // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + PRB - 1u) / PRB);
     const uint32_t wlim = min(SW, job.w - x0s);                             // pixels of this strip that lie in the cell
     const int phase = A.phase_center;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
     C4_ABL_JOB_ONLY();
     C4_ABL_SEGLOAD_ONLY();
-    unsigned char *const wbase = WPJ ? smem + (size_t)wave * L::PER_WAVE : smem;
-    float *s_cxp = reinterpret_cast<float *>(wbase);
-    Rec40 *s_rec = reinterpret_cast<Rec40 *>(wbase + L::CX);
-    unsigned char *wregion = WPJ ? wbase + L::CX + L::REC : smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
+    float *s_cxp = reinterpret_cast<float *>(smem);
+    Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
+    unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
-    // byte offset of record k (k = 1 ...) from smem: 40 (k - 1) + the records' start
-    const uint32_t rec_off = (WPJ ? wave * L::PER_WAVE : 0u) + L::CX - (uint32_t)sizeof(Rec40);
 
-    uint32_t rec_cnt;
-    if constexpr (WPJ) rec_cnt = c4_setup_wave<NS, NCOL>(A, job, seg0, nseg, phase, s_cxp, s_rec);
-    else rec_cnt = c4_setup<NW, RCAP, NS, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, NS, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale * (float)NS;
     const float joff = (float)min_xs * (float)NS + (phase ? 0.5f : 0.0f) - 1.0f;
@@ -211,8 +197,8 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *s_E = wregion;
 
     C4_ABL_SETUP_ONLY();
-    for (uint32_t band0 = band_first; band0 < band_end; band0 += (WPJ ? 1u : NW)) {
-        const uint32_t band = WPJ ? band0 : band0 + wave;
+    for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
+        const uint32_t band = band0 + wave;
         if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
         const uint32_t y0 = band * PRB;
         const uint32_t row_b0 = band * 64u;
@@ -265,26 +251,26 @@ void cov4_kernel(const RenderArgs A)
                 }
                 const uint32_t npairs = tot;
                 uint32_t carry = 0u;               // record index (+ 1) of the last pair walked so far
-              for (uint32_t base = 0; base < npairs; base += L::PCAP) {
+              for (uint32_t base = 0; base < npairs; base += (uint32_t)C4_PCAP) {
                 // markers: slot `off - base` of the chunk holds k + 1 where record k's run starts, 0 elsewhere
-                if (L::PCAP >= 512 || lane < L::PCAP / 8) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
+                if (C4_PCAP >= 512 || lane < C4_PCAP / 8) reinterpret_cast<uint4 *>(s_pairs)[lane] = make_uint4(0, 0, 0, 0);
                 c4_wave_lds_sync();
                 {
                     uint32_t off = off0 - base;    // (wraps below the chunk: an unsigned compare takes both ends)
 #pragma unroll
                     for (int i = 0; i < RPL; ++i) {
-                        if (c[i] && off < L::PCAP) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
+                        if (c[i] && off < (uint32_t)C4_PCAP) s_pairs[off] = (uint16_t)(per * lane + (uint32_t)i + 1u);
                         off += c[i];
                     }
                 }
                 c4_wave_lds_sync();
-                const uint32_t nhere = min(npairs - base, L::PCAP);
+                const uint32_t nhere = min(npairs - base, (uint32_t)C4_PCAP);
                 // one pair per lane per trip; the marker max-scan of the NEXT 64 pairs is issued before the
                 // current 64 are evaluated (an independent chain that fills the evaluation's wait states)
                 uint32_t k_cur = max(c4_wave_incl_max((uint32_t)s_pairs[lane]), carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)k_cur, 63);
                 for (uint32_t p0 = 0; p0 < nhere && C4_ABL_KEEP(3); p0 += 64u) {
-                    const uint32_t pn = min(p0 + 64u + lane, L::PCAP - 1u);
+                    const uint32_t pn = min(p0 + 64u + lane, (uint32_t)C4_PCAP - 1u);
                     const uint32_t s_next = c4_wave_incl_max((uint32_t)s_pairs[pn]);
                     {
                         const uint32_t p = base + p0 + lane, k1 = k_cur;
@@ -297,7 +283,7 @@ void cov4_kernel(const RenderArgs A)
 #else
                         const uint32_t row = (uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u]);
                         // (one 24-bit multiply-add for the record's LDS address, small offsets for its five 8-byte reads)
-                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + rec_off;
+                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
 #endif
                         const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
                         const float cyr = s_cy[row & 63u];
@@ -715,7 +701,7 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
     // (the 1024-record instance — glyphs of 385 .. 768 segments, rare — exists with 32 kept crossings only)
     const int cap = RPL >= 16 ? 32 : (kmax <= 8 ? 8 : (kmax <= 16 ? 16 : 32));
     // the instance as rocprofv3 names it
-    if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, %d, %d, %d, false>", WLOG, cap, RPL, NS);
+    if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, %d, %d, %d>", WLOG, cap, RPL, NS);
     if (!grid.x) return hipSuccess;                // (name only)
     const size_t lds = (cap == 8 ? C4Lds<WLOG, RPL, NS, 8>::TOTAL : (cap == 16 ? C4Lds<WLOG, RPL, NS, 16>::TOTAL : C4Lds<WLOG, RPL, NS, 32>::TOTAL)) + a.lds_pad;
     auto launch = [&](auto kern) -> hipError_t {
@@ -733,22 +719,6 @@ static hipError_t cov4_launch_cap(const RenderArgs &a, dim3 grid, hipStream_t st
     return launch(cov4_kernel<WLOG, 32, RPL, NS>);
 }
 
-// the wave-per-job instance: four cells per workgroup (16 crossings kept, <= 64 records per cell)
-template <int WLOG, int NS>
-static hipError_t cov4_launch_wpj(const RenderArgs &a, bool launch, hipStream_t stream, char *name, size_t name_cap)
-{
-    if (name) snprintf(name, name_cap, "fr::cov4_kernel<%d, 16, 2, %d, true>", WLOG, NS);
-    if (!launch) return hipSuccess;
-    const size_t lds = C4Lds<WLOG, 2, NS, 16, true>::TOTAL + a.lds_pad;
-    auto kern = cov4_kernel<WLOG, 16, 2, NS, true>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3((a.n_jobs + C4_WAVES - 1u) / C4_WAVES), dim3(64 * C4_WAVES), lds, stream, a);
-    return hipGetLastError();
-}
-
 template <int WLOG, int NS>
 static hipError_t cov4_launch_rpl(const RenderArgs &a, uint32_t rec_cap, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
@@ -762,15 +732,8 @@ static hipError_t cov4_launch_rpl(const RenderArgs &a, uint32_t rec_cap, dim3 gr
 // pixel rows; the last of each may be partial), ns x ns samples (ns in {2, 4}), every glyph with <= 384 segments and
 // <= rec_cap (128, 256 or 512) possible root records (checked by fr_plan_create).  launch = false: only name the
 // instance (as rocprofv3 prints it) into `name`.
-hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, int ns, hipStream_t stream, bool launch, char *name, size_t name_cap, bool wpj)
+hipError_t launch_cov4(const RenderArgs &a, uint32_t rec_cap, int ns, hipStream_t stream, bool launch, char *name, size_t name_cap)
 {
-    if (wpj) {      // rec_cap = 64: cells of one 64- / 128-pixel strip, <= 4 bands, glyphs of <= 32 segments (fr_plan_create)
-        if (ns == 4 && a.strip_w == 128u) return cov4_launch_wpj<3, 4>(a, launch, stream, name, name_cap);
-        if (ns == 4 && a.strip_w == 64u) return cov4_launch_wpj<2, 4>(a, launch, stream, name, name_cap);
-        if (ns == 2 && a.strip_w == 128u) return cov4_launch_wpj<3, 2>(a, launch, stream, name, name_cap);
-        if (ns == 2 && a.strip_w == 64u) return cov4_launch_wpj<2, 2>(a, launch, stream, name, name_cap);
-        return hipErrorInvalidValue;
-    }
     const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);
     if (ns == 4) {
         if (a.strip_w == 256u) return cov4_launch_rpl<4, 4>(a, rec_cap, grid, stream, name, name_cap);

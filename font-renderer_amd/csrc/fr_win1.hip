@@ -30,11 +30,11 @@ namespace fr {
 enum { MODE1_WINDING_I16 = 0, MODE1_GRAY_DEBUG = 1, MODE1_MASK = 2, MODE1_BITS = 3 };
 enum { W1_ROWS = 16 };
 
-template <int WLOG, int RPL, bool WPJ = false>
+template <int WLOG, int RPL>
 struct W1Lds {
     static constexpr uint32_t NCOL = 16u << WLOG;                           // sample columns = pixels of a strip
     static constexpr uint32_t CX = ((NCOL + 2u) * 4u + 15u) & ~15u;
-    static constexpr uint32_t RCAP = WPJ ? 64u : 64u * RPL;                 // (wave-per-job: per WAVE)
+    static constexpr uint32_t RCAP = 64u * RPL;
     static constexpr uint32_t REC = RCAP * (uint32_t)sizeof(Rec40);
     // pairs per round (one row has <= RCAP).  The two-records-per-lane instances take 128 and settle an over-full row in
     // registers (below) instead of in the marker array: that is what lets SIX of their workgroups share a CU at 256-pixel strips
@@ -51,9 +51,7 @@ struct W1Lds {
     static constexpr uint32_t OFF_WAVES = CX + REC;
     static constexpr uint32_t OFF_WCNT = OFF_WAVES + C4_WAVES * WAVE;
     static constexpr uint32_t OFF_CYT = OFF_WCNT + 64u;                     // ray heights of the cell's rows (cells of <= 256 rows)
-    // wave-per-job: every wave has its own cx table, records, walk region and ray heights (cells of <= 64 rows)
-    static constexpr uint32_t PER_WAVE = CX + REC + WAVE + 256u;
-    static constexpr uint32_t TOTAL = WPJ ? C4_WAVES * PER_WAVE : OFF_CYT + 1024u;
+    static constexpr uint32_t TOTAL = OFF_CYT + 1024u;
 };
 
 __device__ __forceinline__ uint32_t w1_gray(int w)
@@ -92,14 +90,11 @@ __device__ __forceinline__ void w1_store_bits(unsigned char *row, uint32_t wx, u
     if (ok && (wx & 3u) == 0u) { const uint2 v = make_uint2(pair, d1); __builtin_memcpy(row + 2u * wx, &v, 8); }
 }
 
-// WPJ ("wave per job"): small cells of small glyphs — one strip wide, at most 4 bands (64 rows) tall, <= 32 segments: text
-// sizes — get a WAVE each instead of a workgroup (as cov4_kernel's: fr_cov4.hip)
-template <int WLOG, int MODE, int RPL, bool WPJ = false>
+template <int WLOG, int MODE, int RPL>
 __global__ __launch_bounds__(64 * C4_WAVES) __attribute__((amdgpu_waves_per_eu(w1_occ(RPL, WLOG), w1_occ(RPL, WLOG))))
 void win1_kernel(const RenderArgs A)
 {
-    using L = W1Lds<WLOG, RPL, WPJ>;
-    static_assert(!WPJ || RPL == 2, "wave-per-job instances keep two records per lane");
+    using L = W1Lds<WLOG, RPL>;
     constexpr uint32_t NW = C4_WAVES;
     constexpr uint32_t RCAP = L::RCAP;
     constexpr uint32_t NCOL = L::NCOL;              // pixels of a strip
@@ -110,47 +105,34 @@ void win1_kernel(const RenderArgs A)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
-    if (!WPJ && A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
-    if (!WPJ && A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
-    const uint32_t jidx = WPJ ? bid * NW + wave : bid;                      // (wave-per-job: one strip, all bands, my own cell)
-    if (WPJ && jidx >= A.n_jobs) return;
+    if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
+    if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
+    const uint32_t jidx = bid;
     const Job job = A.jobs[jidx];
     const uint32_t x0s = strip * NCOL;
-    const uint32_t band_first = WPJ ? 0u : bgrp * A.bands_per_wg;           // bands of 16 pixel rows
-    if (band_first * W1_ROWS >= job.h || x0s >= job.w) return;             // workgroup-uniform (wave-per-job: my wave's own)
-    const uint32_t band_end = WPJ ? (job.h + W1_ROWS - 1u) / W1_ROWS : min(band_first + A.bands_per_wg, (job.h + W1_ROWS - 1u) / W1_ROWS);
+    const uint32_t band_first = bgrp * A.bands_per_wg;                      // bands of 16 pixel rows
+    if (band_first * W1_ROWS >= job.h || x0s >= job.w) return;             // workgroup-uniform
+    const uint32_t band_end = min(band_first + A.bands_per_wg, (job.h + W1_ROWS - 1u) / W1_ROWS);
     const uint32_t wlim = min(NCOL, job.w - x0s);                           // pixels of this strip that lie in the cell
     const int phase = A.phase_center;
     const uint32_t seg0 = A.job_seg[2u * (size_t)jidx], nseg = A.job_seg[2u * (size_t)jidx + 1u];
 
-    unsigned char *const wbase = WPJ ? smem + (size_t)wave * L::PER_WAVE : smem;
-    float *s_cxp = reinterpret_cast<float *>(wbase);
-    Rec40 *s_rec = reinterpret_cast<Rec40 *>(wbase + L::CX);
-    unsigned char *wregion = WPJ ? wbase + L::CX + L::REC : smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
+    float *s_cxp = reinterpret_cast<float *>(smem);
+    Rec40 *s_rec = reinterpret_cast<Rec40 *>(smem + L::CX);
+    unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
-    const uint32_t rec_off = (WPJ ? wave * L::PER_WAVE : 0u) + L::CX - (uint32_t)sizeof(Rec40);     // byte offset of record k = 1 ... from smem, less 40 k
 
     const float soff = phase ? 0.5f : 0.0f;
     // cells of up to 256 rows: every row's ray height cy = (f32(max_y - y) - off) / scale (:27) is computed once — the
     // set-up looks at four rows per candidate and every band at 16, each of them a division otherwise
     const float *cyt = nullptr;
-    uint32_t rec_cnt;
-    if constexpr (WPJ) {
-        // (my own cell: <= 64 rows, one ray height per lane; the rows beyond the cell are never looked at)
-        float *t = reinterpret_cast<float *>(wbase + L::CX + L::REC + L::WAVE);
-        t[lane] = ((float)(job.max_y - (int32_t)lane) - soff) / job.scale;
-        c4_wave_lds_sync();
+    if (job.h <= 256u) {                                                    // (workgroup-uniform)
+        float *t = reinterpret_cast<float *>(smem + L::OFF_CYT);
+        if (tid < job.h) t[tid] = ((float)(job.max_y - (int32_t)tid) - soff) / job.scale;
+        __syncthreads();
         cyt = t;
-        rec_cnt = c4_setup_wave<1, NCOL>(A, job, seg0, nseg, phase, s_cxp, s_rec, cyt);
-    } else {
-        if (job.h <= 256u) {                                                // (workgroup-uniform)
-            float *t = reinterpret_cast<float *>(smem + L::OFF_CYT);
-            if (tid < job.h) t[tid] = ((float)(job.max_y - (int32_t)tid) - soff) / job.scale;
-            __syncthreads();
-            cyt = t;
-        }
-        rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES), cyt);
     }
+    const uint32_t rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES), cyt);
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale;
     const float joff = (float)min_xs + soff - 1.0f;
@@ -174,8 +156,8 @@ void win1_kernel(const RenderArgs A)
     int16_t *s_roff = reinterpret_cast<int16_t *>(wregion + L::OFF_ROFF);
     const uint32_t wx = lane & (NWIN - 1u);
 
-    for (uint32_t band0 = band_first; band0 < band_end; band0 += (WPJ ? 1u : NW)) {
-        const uint32_t band = WPJ ? band0 : band0 + wave;
+    for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
+        const uint32_t band = band0 + wave;
         if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
         const uint32_t y0 = band * W1_ROWS;         // first pixel row = first sample row of my band
         // ray height of row `lane & 15`: cy = (f32(max_y - y) - off) / scale   (:27)
@@ -242,7 +224,7 @@ void win1_kernel(const RenderArgs A)
                         const uint32_t p = p0 + lane, k1 = k_cur;
                         const bool livep = p < npairs;
                         const uint32_t row = ((uint32_t)((int32_t)p + (int32_t)s_roff[k1 - 1u])) & 15u;
-                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + rec_off;
+                        const uint32_t raddr = __umul24(k1, (uint32_t)sizeof(Rec40)) + (L::CX - (uint32_t)sizeof(Rec40));
                         const Rec40 r = *reinterpret_cast<const Rec40 *>(smem + raddr);
                         const float cyr = s_cy[row];
                         // the reference's operation order, one rounding per operation (:51, :58-61, :53/:65, :67); the row
@@ -557,7 +539,7 @@ template <int WLOG, int RPL>
 static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
     const size_t lds = W1Lds<WLOG, RPL>::TOTAL + a.lds_pad;
-    if (name) snprintf(name, name_cap, "fr::win1_kernel<%d, %d, %d, false>", WLOG, mode, RPL);      // as rocprofv3 names the instance
+    if (name) snprintf(name, name_cap, "fr::win1_kernel<%d, %d, %d>", WLOG, mode, RPL);      // as rocprofv3 names the instance
     if (!grid.x) return hipSuccess;               // (name only)
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {
@@ -573,24 +555,6 @@ static hipError_t win1_launch_mode(const RenderArgs &a, int mode, dim3 grid, hip
     return launch(win1_kernel<WLOG, MODE1_MASK, RPL>);
 }
 
-// the wave-per-job instance: four cells per workgroup (<= 64 records per cell)
-template <int WLOG>
-static hipError_t win1_launch_wpj(const RenderArgs &a, int mode, bool launch, hipStream_t stream, char *name, size_t name_cap)
-{
-    if (name) snprintf(name, name_cap, "fr::win1_kernel<%d, %d, 2, true>", WLOG, mode);
-    if (!launch) return hipSuccess;
-    const size_t lds = W1Lds<WLOG, 2, true>::TOTAL + a.lds_pad;
-    const dim3 grid((a.n_jobs + C4_WAVES - 1u) / C4_WAVES);
-    auto go = [&](auto kern) -> hipError_t {
-        hipLaunchKernelGGL(kern, grid, dim3(64 * C4_WAVES), lds, stream, a);
-        return hipGetLastError();
-    };
-    if (mode == MODE1_WINDING_I16) return go(win1_kernel<WLOG, MODE1_WINDING_I16, 2, true>);
-    if (mode == MODE1_GRAY_DEBUG) return go(win1_kernel<WLOG, MODE1_GRAY_DEBUG, 2, true>);
-    if (mode == MODE1_BITS) return go(win1_kernel<WLOG, MODE1_BITS, 2, true>);
-    return go(win1_kernel<WLOG, MODE1_MASK, 2, true>);
-}
-
 template <int WLOG>
 static hipError_t win1_launch_rpl(const RenderArgs &a, int mode, uint32_t rec_cap, dim3 grid, hipStream_t stream, char *name, size_t name_cap)
 {
@@ -603,13 +567,8 @@ static hipError_t win1_launch_rpl(const RenderArgs &a, int mode, uint32_t rec_ca
 // jobs: cells of any size up to 2048 rows (strips of a.strip_w in {64, 128, 256} pixels and bands of 16 rows; the last of
 // each may be partial), one sample per pixel, glyphs with <= 384 segments and <= rec_cap possible root records.
 // mode: 0 winding_i16, 1 gray_debug, 2 mask, 3 sign bits (one per pixel, job-local bit plane).  launch = false: only name the instance (as rocprofv3 prints it).
-hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream, bool launch, char *name, size_t name_cap, bool wpj)
+hipError_t launch_win1(const RenderArgs &a, int mode, uint32_t rec_cap, hipStream_t stream, bool launch, char *name, size_t name_cap)
 {
-    if (wpj) {      // rec_cap = 64: cells of one 64- / 128-pixel strip, <= 64 rows, glyphs of <= 32 segments (fr_plan_create)
-        if (a.strip_w == 128u) return win1_launch_wpj<3>(a, mode, launch, stream, name, name_cap);
-        if (a.strip_w == 64u) return win1_launch_wpj<2>(a, mode, launch, stream, name, name_cap);
-        return hipErrorInvalidValue;
-    }
     const dim3 grid(launch ? (uint32_t)((size_t)a.n_jobs * a.band_groups * a.strips) : 0u);
     if (a.strip_w == 256u) return win1_launch_rpl<4>(a, mode, rec_cap, grid, stream, name, name_cap);
     if (a.strip_w == 128u) return win1_launch_rpl<3>(a, mode, rec_cap, grid, stream, name, name_cap);

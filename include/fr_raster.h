@@ -105,8 +105,7 @@ int fr_ctx_sync(fr_ctx *ctx);
  * exact direct-sum fallback: rounded up to 8, 16 or 32; default 32), "strip_px" (column
  * strip width in pixels, multiple of 16, <= 256: wider cells are rendered strip by strip; the fast kernels use
  * the largest of 64 / 128 / 256 that does not exceed it),
- * "cov4" (0: every job takes the general kernel), "wpj" (0: small cells of small glyphs get a workgroup each
- * like every other cell, instead of a wave each), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
+ * "cov4" (0: every job takes the general kernel), "sdf_cull" (0: FR_SDF_U8 looks at every segment from
  * every pixel — the culls are exact, this is how the tests show it), "zero_copy" (1: fr_render_glyph renders small
  * glyphs straight from / into pinned host memory; measured no faster, off by default), "overlap" (a plan that needs several kernel launches forks the
  * smaller ones onto an internal second stream and joins them: 1 (default) for plans of >= 32 Mpixel — below that one

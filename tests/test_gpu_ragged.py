@@ -100,7 +100,7 @@ def test_two_by_two_samples_on_cov4(ctx, oracle, segs, cell):
         dgs = fr.DeviceGlyphSet(ctx, gs)
         for center in (False, True):
             got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, O.COVERAGE_U8, atlas_shape(len(gs), cell, 3), 2, center, dgs, 0,
-                                   ["fr::cov4_kernel<", ", 2, false> x"])
+                                   ["fr::cov4_kernel<", ", 2> x"])
             assert np.array_equal(got, ref), (segs, cell, center, desc)
             assert set(np.unique(ref)) <= {0x5b, 0, 64, 128, 191, 255}
         dgs.close()
@@ -256,33 +256,4 @@ def test_glyphs_of_385_to_768_segments_take_the_1024_record_instances(ctx, oracl
     for mode, omode, n, center in [ONE[1], ONE[0], (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 4, True), (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 2, False), (fr.FR_SDF_U8, O.SDF_U8, 1, True)]:
         got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, atlas_shape(len(gs), 256, 3), n, center, dgs, 0, [", 16" if n == 1 else ", 16, "])
         assert np.array_equal(got, ref), (segs, mode, n, desc)
-    dgs.close()
-
-
-def test_wave_per_job_instances_on_text_sized_images(ctx, oracle, ascii_set):
-    """small cells of small glyphs (one 64- / 128-pixel strip, <= 4 bands, <= 32 segments: text sizes) get a WAVE each —
-    four cells per workgroup, every wave with its own cx table, records and set-up.  190 real glyphs at renderGlyph's own
-    sizes for font sizes 12 .. 60, every mode: == the oracle, == the workgroup-per-job instances (ctx option wpj = 0),
-    and the plan does use both kinds (glyphs of more than 32 segments stay with a workgroup)."""
-    gs = ascii_set.gs
-    parts, y = [], 0
-    for size in (12, 17, 24, 33, 48, 60):
-        jb, h = glyph_dims_jobs(gs, size, ascii_set.g_upm, 1499)
-        jb["out_y"] += y
-        y += h
-        parts.append(jb)
-    jobs = np.concatenate(parts)
-    dgs = fr.DeviceGlyphSet(ctx, gs)
-    for mode, omode, n, center in ONE + [(fr.FR_COVERAGE_U8, O.COVERAGE_U8, 4, True), (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 2, False), (fr.FR_SDF_U8, O.SDF_U8, 1, False)]:
-        got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, (y + 1, 1499), n, center, dgs, 0, [", true> x", ", false> x"])
-        assert np.array_equal(got, ref), (mode, n, desc)
-        try:
-            ctx.set_option("wpj", 0)
-            plain, _, desc0 = _both(ctx, oracle, gs, jobs[:1], mode, omode, (y + 1, 1499), n, center, dgs)     # (describe only)
-            assert "true>" not in desc0
-            again = np.full_like(got, 0x5b)
-            rg.render_batch(dgs, jobs, mode, again, n, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
-        finally:
-            ctx.set_option("wpj", 1)
-        assert np.array_equal(again, got), (mode, n)
     dgs.close()
