@@ -20,7 +20,7 @@ bad = 0
 for case in range(cases):
     kind = rng.random()
     if kind < 0.4:
-        S = int(rng.choice([3, 5, 8, 16, 31, 64, 100, 128, 140, 200, 256, 300]))
+        S = int(rng.choice([3, 5, 8, 16, 31, 64, 100, 128, 140, 200, 256, 300, 390, 512, 700, 800]))
         gs = synth_glyphset(int(rng.integers(1, 5)), S, first_index=int(rng.integers(0, 1 << 20)))
         upm = 2048
     elif kind < 0.55:
@@ -45,7 +45,7 @@ for case in range(cases):
             if rng.random() < 0.1:
                 w -= int(rng.integers(1, 9))            # one odd cell: the plan becomes mixed
         if mode == 4:
-            w, h = min(w, 40), min(h, 40)
+            w, h = min(w, 150), min(h, 90)
         fs = int(rng.integers(4, 400))
         s = np.float32(fs) / np.float32(upm)
         box = gs.boxes[g].astype(np.float32)
