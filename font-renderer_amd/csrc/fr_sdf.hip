@@ -51,7 +51,8 @@ constexpr uint32_t SDF_ENTRY = 28u;           // floats per staged segment (7 x 
 // |B(t) - q|^2 minimised over t in [0,1] as the header defines it; `e` is the staged entry.  The probe points
 // B(k/8) = (p0 + (2t) A) + (t t) D are the same roundings as the header's expression tree — 2t and t t are exact
 // for t = k/8 — only hoisted out of the pixel.
-__device__ __forceinline__ float seg_dist2(const float *e, float qx, float qy)
+// `want`: this lane's result will be used (the others ride along and must not hold the wave in the Newton loop)
+__device__ __forceinline__ float seg_dist2(const float *e, float qx, float qy, bool want = true)
 {
     const float4 pa = *reinterpret_cast<const float4 *>(e);
     const float2 dd = *reinterpret_cast<const float2 *>(e + 10);
@@ -83,8 +84,12 @@ __device__ __forceinline__ float seg_dist2(const float *e, float qx, float qy)
         const float dx = 2.0f * (ax + t * bx), dy = 2.0f * (ay + t * by);
         const float f = x * dx + y * dy;
         const float fp = dx * dx + dy * dy + 2.0f * (x * bx + y * by);
+        const float t0 = t;
         if (fp > 0.0f) t = t - f / fp;
         t = fminf(fmaxf(t, lo), hi);
+        // a step is a function of t alone: once NO lane's t moved, the remaining steps would return the same t again —
+        // leaving here gives the very bytes of four steps (the CPU twin always takes four)
+        if (__all(!want || t == t0)) break;
     }
     {
         const float x = p0x + 2.0f * t * ax + t * t * bx - qx;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(64) void sdf_kernel(const Job *__restrict__ jobs, c
 #if defined(FR_SDF_ABLATE) && FR_SDF_ABLATE == 1
                 const float d2 = cull == 7 ? seg_dist2(e, qx, qy) : g2 + 1.0f;                  // timing-only: no distance evaluation
 #else
-                const float d2 = seg_dist2(e, qx, qy);
+                const float d2 = seg_dist2(e, qx, qy, active);
 #endif
                 if (active && d2 < best) best = d2;
             }
