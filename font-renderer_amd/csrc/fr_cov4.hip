@@ -356,11 +356,7 @@ void cov4_kernel(const RenderArgs A)
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min(PRB, job.h - y0);
-        #ifdef FR_NO_RAGGED   // timing-only experiment: whole cells only
-        const bool edge = false;
-#else
-        const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < SW) | (hlim < PRB))) != 0;
-#endif
+                const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < SW) | (hlim < PRB))) != 0;
         if (__ballot(cnt != 0u) == 0ull) {
             // no crossing on any of my 64 sample rows: every winding is 0 — store the band's background
             for (uint32_t yl = lane >> WLOG; yl < PRB; yl += (64u >> WLOG)) {

@@ -277,11 +277,7 @@ void win1_kernel(const RenderArgs A)
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
         // (wave-uniform — a whole cell never takes the clipped stores)
         const uint32_t hlim = min((uint32_t)W1_ROWS, job.h - y0);
-        #ifdef FR_NO_RAGGED   // timing-only experiment: whole cells only
-        const bool edge = false;
-#else
-        const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < NCOL) | (hlim < (uint32_t)W1_ROWS))) != 0;
-#endif
+                const bool edge = __builtin_amdgcn_readfirstlane((int)((wlim < NCOL) | (hlim < (uint32_t)W1_ROWS))) != 0;
         if ((__ballot(cnt != 0u) & 0xffffull) == 0ull) {
             // no crossing on any of my 16 rows: every winding is 0
             const uint32_t bg = (MODE == MODE1_GRAY_DEBUG) ? 0x64646464u : 0u;      // clamp(0 * 20 + 100) (:28)
