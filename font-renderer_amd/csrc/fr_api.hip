@@ -76,7 +76,7 @@ struct fr_ctx {
     uint32_t fuse_prepare = 1;   // build root records inside the render kernel when every glyph has <= 128 segments
     uint32_t lds_pad = 0;        // experiment knob: extra dynamic LDS bytes per workgroup (occupancy studies)
     uint32_t min_wgs = 2048;     // split a cell's bands over workgroups below this many workgroups
-    uint32_t cov4 = 1;           // 16-sample coverage of uniform cells takes cov4_kernel (fr_cov4.hip) where it fits
+    uint32_t cov4 = 1;           // jobs take the fast kernels (cov4_kernel / win1_kernel) where they fit (fast_class); 0: all general
     uint32_t zero_copy = 0;      // fr_render_glyph: render small glyphs from / into pinned host memory directly (measured: no faster than two small copies; off)
     uint32_t sdf_cull = 1;       // FR_SDF_U8: drop segments that cannot change a tile / a pixel (exact; 0 = look at all, for tests)
     uint32_t overlap = 1;        // a plan's smaller launches run beside its largest one on a second stream: 0 never, 1 plans of >= 32 Mpixel, 2 always

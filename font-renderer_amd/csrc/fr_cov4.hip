@@ -1,9 +1,9 @@
-// fr_cov4.hip — the headline instance of the hot path: 16-sample (4 x 4) anti-aliased coverage of atlas
-// cells, rebuilt around what bounds it on gfx950.  Same integers as render_kernel<COVERAGE_U8, 4> of
+// fr_cov4.hip — the headline instance of the hot path: 16-sample (4 x 4; also 2 x 2) anti-aliased coverage of
+// cells of any size, rebuilt around what bounds it on gfx950.  Same integers as render_kernel<COVERAGE_U8, 4> of
 // fr_render.hip (and therefore as the reference's glyphWindingAt per sample,
 // /root/reference/src/tools/render_glyph.zig:35-73, non-zero fill :29, box filter = the MSAA average
-// resolve of VulkanContext.zig:307-313); a plan takes this kernel for every job it fits (uniform cells,
-// <= 256 live root records) and the general kernel for the rest.
+// resolve of VulkanContext.zig:307-313); a plan takes this kernel for every job it fits (any width and height up to
+// 2048 sample rows, glyphs of <= 768 segments: fr_api.hip, fast_class) and the general kernel for the rest.
 //
 // What the round-2 measurements say (tools/ubench/issue_model*.hip, profiles/r02/issue_model*.txt):
 // the path is bound by VECTOR-ALU ISSUE TIME — scalar, LDS and branch instructions of one wave hide under

@@ -1,6 +1,7 @@
 // fr_win1.hip — the reference's own products at one sample per pixel: Image.Winding (int16 winding numbers),
 // renderGlyph's gray map clamp(w * 20 + 100) (/root/reference/src/tools/render_glyph.zig:28) and the non-zero mask
-// (:29), for atlas cells (uniform plans); the general render_kernel keeps every other shape.
+// (:29), for cells of any width and height (renderGlyph's own image sizes included, :14-19) of glyphs of <= 768
+// segments; the general render_kernel keeps the rest.
 //
 // Same integers as glyphWindingAt per pixel (:35-73): winding(x) = sum over accepted roots of step [x < J].
 // With one sample per pixel there is no inside/outside rule to apply per sample row, so nothing has to be sorted:

@@ -139,7 +139,7 @@ int fr_plan_create(fr_ctx *ctx, const fr_glyphset *gs, const fr_job *jobs, uint3
                    const fr_raster_params *params, fr_plan **out);
 void fr_plan_destroy(fr_plan *plan);
 /* Every render starts from the glyph POINTS (nothing derived is reused between renders): the render
- * kernels build the root records of a glyph of <= 128 (general kernel) / <= 256 (cov4 kernel) segments
+ * kernels build the root records of a glyph of <= 128 (general kernel) / <= 768 (cov4 / win1 kernels) segments
  * themselves, in LDS ("fused", decided per job); the precompute kernel is re-run first for the larger glyphs only.
  * Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
  * out_rows rows of out_stride elements (u8, or i16 for FR_WINDING_I16); every job
@@ -151,7 +151,7 @@ uint64_t fr_plan_pixels(const fr_plan *plan);   /* sum of w*h over the jobs */
 /* how the plan's jobs are split between the render kernels (the decision is per job): the fast kernels — cov4_kernel
  * (4 x 4 or 2 x 2 samples) / win1_kernel (one sample per pixel) — take cells of ANY width and height up to 2048 sample
  * rows (renderGlyph's own image sizes, render_glyph.zig:14-19, included: strips of 64 / 128 / 256 pixels chosen from
- * the job's width, stores clipped at the cell's border) of glyphs with <= 384 segments; the general render_kernel takes
+ * the job's width, stores clipped at the cell's border) of glyphs with <= 768 segments; the general render_kernel takes
  * everything else                                                                                              */
 int fr_plan_stats(const fr_plan *plan, uint32_t *n_jobs_cov4, uint32_t *n_jobs_general);
 /* the kernel instances one render of the plan launches, as rocprofv3 --kernel-trace names them, each with its job
