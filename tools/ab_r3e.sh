@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on the GPU box: occupancy of the 16-crossing instances (list rows now CAP + 4 slots) and the dense gather of over-full rows
+# A/B on the GPU box: occupancy of the 16-crossing instances (list rows CAP + 4 slots) and the dense gather of over-full rows.
+# Variant libraries: make -C font-renderer_amd/csrc variant NAME=occ6 DEFS=-DFR_C4_OCC_SMALL=6 (4 / 8 likewise; FR_W1_OCC_SMALL for win1)
 out=gpurun_out/r3e; mkdir -p $out
 run() { # name lib workload extra...
   name=$1; lib=$2; w=$3; shift 3

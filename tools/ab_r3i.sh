@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B: the round-2 tree (.ab_r02, built from 9a0dd80) against this tree, alternating
+# same-box A/B: the round-2 tree against this tree, alternating.  Set-up (here, before gpurun; untracked, travels with the
+# snapshot):  mkdir .ab_r02 && git archive 9a0dd80 | tar -x -C .ab_r02 && make -C .ab_r02/font-renderer_amd/csrc -j6 && make -C .ab_r02/oracle
 out=gpurun_out/r3i; mkdir -p $out
 for rep in 1; do
 for w in c3_cjk21k_256px_s128_16spp c3_cjk21k_256px_s128_gray_debug c3_strokes21k_256px_s128_16spp c3_cjk21k_256px_s128_winding_i16; do
