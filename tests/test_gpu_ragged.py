@@ -257,3 +257,49 @@ def test_glyphs_of_385_to_768_segments_take_the_1024_record_instances(ctx, oracl
         got, ref, desc = _both(ctx, oracle, gs, jobs, mode, omode, atlas_shape(len(gs), 256, 3), n, center, dgs, 0, [", 16" if n == 1 else ", 16, "])
         assert np.array_equal(got, ref), (segs, mode, n, desc)
     dgs.close()
+
+
+def test_whole_font_at_renderglyph_sizes_properties(ctx, oracle):
+    """the reference's literal product on a whole real font (every loadable glyph of DejaVuSerif-Italic through the C-side
+    producer, three font sizes, ~9 400 images shelf-packed): nothing on the general kernel, two renders equal, the bytes
+    around the images untouched, and 90 images spread over the batch == the oracle (gray map and 16-sample coverage)."""
+    import os
+    import torch
+    path = "/usr/local/lib/python3.10/dist-packages/matplotlib/mpl-data/fonts/ttf/DejaVuSerif-Italic.ttf"
+    if not os.path.exists(path):
+        pytest.skip("DejaVuSerif-Italic.ttf not in this image")
+    font = fr.Font.initTTF(path)
+    gs, kept = font.glyphset()
+    upm = font.information.units_per_em
+    parts, y, W = [], 0, 4099
+    for size in (16, 40, 100):
+        jb, h = glyph_dims_jobs(gs, size, upm, W)
+        jb["out_y"] += y
+        y += h + 1                                       # (a row of sentinel bytes between the runs of shelves)
+        parts.append(jb)
+    jobs = np.concatenate(parts)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(len(jobs), 90, replace=False))
+    for mode, omode, n, center in ((fr.FR_GRAY_DEBUG, O.GRAY_DEBUG, 1, False), (fr.FR_COVERAGE_U8, O.COVERAGE_U8, 4, True)):
+        plan = fr.Plan(dgs, jobs, mode, n, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+        assert plan.stats()["jobs_general"] == 0, plan.describe()
+        a = torch.full((y, W), 0x5b, dtype=torch.uint8, device="cuda")
+        b = torch.full((y, W), 0x5b, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        plan.render(a.data_ptr(), W, y); plan.render(b.data_ptr(), W, y); ctx.sync()
+        plan.close()
+        assert torch.equal(a, b)
+        host = a.cpu().numpy()
+        covered = np.zeros((y, W), bool)
+        for j in jobs:
+            covered[j["out_y"]:j["out_y"] + j["h"], j["out_x"]:j["out_x"] + j["w"]] = True
+        assert (host[~covered] == 0x5b).all()                                  # nothing outside the images was written
+        for k in pick:
+            j = jobs[k:k + 1].copy()
+            ref = np.zeros((int(j["h"][0]), int(j["w"][0])), np.uint8)
+            one = j.copy(); one["out_x"] = 0; one["out_y"] = 0
+            oracle.render_batch(gs, one, omode, ref, n, center, 4)
+            got = host[j["out_y"][0]:j["out_y"][0] + j["h"][0], j["out_x"][0]:j["out_x"][0] + j["w"][0]]
+            assert np.array_equal(got, ref), (mode, int(k))
+    dgs.close()
