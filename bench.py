@@ -52,6 +52,8 @@ WORKLOADS = {
     "c3_cjk21k_256px_s128_4spp": dict(glyphs=20992, cell=256, segs=128, n=2, cols=64),
     # glyphs too large for the fast kernels (512 segments > 384): what is left on the general render_kernel
     "big_s512_2048cells_256px_16spp": dict(glyphs=2048, cell=256, segs=512, n=4, cols=64),
+    # what is LEFT on the general render_kernel: glyphs of more than 768 segments
+    "huge_s1024_512cells_256px_16spp": dict(glyphs=512, cell=256, segs=1024, n=4, cols=32),
     # stroke-dense outlines: 8-16 thin strokes per glyph, 10-30 crossings per ray (synth.stroke_glyph)
     "c3_strokes21k_256px_s128_16spp": dict(glyphs=20992, cell=256, segs=128, n=4, cols=64, gen="stroke"),
     # a real font through the C-side contour producer (fr_font_*): every glyph of DejaVuSerif-Italic the
