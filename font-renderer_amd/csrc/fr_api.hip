@@ -80,6 +80,8 @@ struct fr_ctx {
     uint32_t zero_copy = 0;      // fr_render_glyph: render small glyphs from / into pinned host memory directly (measured: no faster than two small copies; off)
     uint32_t sdf_cull = 1;       // FR_SDF_U8: drop segments that cannot change a tile / a pixel (exact; 0 = look at all, for tests)
     uint32_t overlap = 1;        // a plan's smaller launches run beside its largest one on a second stream: 0 never, 1 plans of >= 32 Mpixel, 2 always
+    uint32_t graph = 0;          // 1: a plan's launches are captured into a hipGraph at its first render to a destination and replayed afterwards
+    uint32_t opt_epoch = 0;      // bumped by every fr_ctx_set_option: a captured graph is only replayed under the options it was captured with
     hipStream_t aux = nullptr;   // that second stream and the fork / join events, created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scratch of the single-glyph entry point (fr_render_glyph): one device arena and one host staging
@@ -126,6 +128,11 @@ struct fr_plan {
     bool uniform = false;        // see fr_plan_create
     uint64_t pixels = 0, need_cols = 0, need_rows = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // option "graph": the launches of one render as an instantiated hipGraph, and what it was captured for
+    hipGraphExec_t gexec = nullptr;
+    void *g_out = nullptr;
+    size_t g_stride = 0, g_rows = 0;
+    uint32_t g_epoch = 0;
 };
 
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
@@ -188,6 +195,8 @@ int fr_ctx_sync(fr_ctx *ctx)
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value)
 {
     if (!ctx || !key) return fail(FR_E_INVALID, "fr_ctx_set_option: NULL argument");
+    ++ctx->opt_epoch;
+    if (!strcmp(key, "graph")) { ctx->graph = value ? 1u : 0u; return FR_OK; }
     if (!strcmp(key, "kmax")) {
         if (value < 1 || value > 128) return fail(FR_E_INVALID, "kmax must be in [1,128]");
         ctx->kmax = (uint32_t)value;
@@ -516,6 +525,7 @@ void fr_plan_destroy(fr_plan *plan)
     dfree(plan->d_jobs); dfree(plan->d_job_seg); dfree(plan->d_large); dfree(plan->d_bits); dfree(plan->d_job_bits);
     if (plan->ev0) (void)hipEventDestroy(plan->ev0);
     if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+    if (plan->gexec) (void)hipGraphExecDestroy(plan->gexec);
     delete plan;
 }
 
@@ -704,7 +714,17 @@ int fr_plan_describe(const fr_plan *plan, char *buf, size_t cap)
     return FR_OK;
 }
 
-static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
+static int ensure_aux(fr_ctx *ctx)
+{
+    if (!ctx->aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    return FR_OK;
+}
+
+static int plan_check(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
 {
     if (!plan) return fail(FR_E_INVALID, "plan is NULL");
     if (plan->n_jobs == 0) return FR_OK;
@@ -712,6 +732,14 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     if (plan->need_cols > out_stride || plan->need_rows > out_rows)
         return fail(FR_E_INVALID, "jobs need %llu x %llu elements, output is %zu x %zu",
                     (unsigned long long)plan->need_cols, (unsigned long long)plan->need_rows, out_stride, out_rows);
+    return FR_OK;
+}
+
+// the launches of one render, issued on the context's stream(s)
+static int plan_launch_direct(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
+{
+    if (const int rc = plan_check(plan, out_dev, out_stride, out_rows)) return rc;
+    if (plan->n_jobs == 0) return FR_OK;
     HIP_TRY(hipSetDevice(plan->ctx->device));
     const uint32_t n_fast = plan->n_fast, n_gen = plan->n_jobs - plan->n_fast;
     const bool sdf = plan->params.mode == FR_SDF_U8;
@@ -757,11 +785,7 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
     // on one stream than through a fork and a join: measured 0.038 vs 0.056 ms at 5.8 Mpixel, 0.373 vs 0.356 at 221 Mpixel)
     const bool forked = ctx->overlap && n_fast && n_launches > 1 && (ctx->overlap == 2u || plan->pixels >= ((uint64_t)32 << 20));
     if (forked) {
-        if (!ctx->aux) {
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
+        if (const int rc = ensure_aux(ctx)) return rc;
         HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         gst = ctx->aux;
@@ -823,6 +847,38 @@ static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t o
         a.n_jobs = plan->n_jobs;
         HIP_TRY(fr::launch_sdf(a, plan->max_w, plan->max_h, plan->gs->max_seg_per_glyph, (int)plan->ctx->sdf_cull, plan->ctx->stream));
     }
+    return FR_OK;
+}
+
+// One render of a plan.  Option "graph": the same launches — the fork onto the second stream and the join included — are
+// captured once per destination into a hipGraph and replayed with ONE hipGraphLaunch afterwards (the capture is redone when
+// the destination or a context option changes).
+static int plan_launch(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows)
+{
+    if (const int rc = plan_check(plan, out_dev, out_stride, out_rows)) return rc;
+    if (plan->n_jobs == 0) return FR_OK;
+    fr_ctx *const ctx = plan->ctx;
+    if (!ctx->graph) return plan_launch_direct(plan, out_dev, out_stride, out_rows);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (plan->gexec && (plan->g_out != out_dev || plan->g_stride != out_stride || plan->g_rows != out_rows || plan->g_epoch != ctx->opt_epoch)) {
+        (void)hipGraphExecDestroy(plan->gexec);
+        plan->gexec = nullptr;
+    }
+    if (!plan->gexec) {
+        if (const int rc = ensure_aux(ctx)) return rc;        // (nothing is created while the capture is open)
+        HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+        const int rc = plan_launch_direct(plan, out_dev, out_stride, out_rows);
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        HIP_TRY(ce);
+        const hipError_t ie = hipGraphInstantiate(&plan->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) plan->gexec = nullptr;
+        HIP_TRY(ie);
+        plan->g_out = out_dev; plan->g_stride = out_stride; plan->g_rows = out_rows; plan->g_epoch = ctx->opt_epoch;
+    }
+    HIP_TRY(hipGraphLaunch(plan->gexec, ctx->stream));
     return FR_OK;
 }
 
@@ -1071,7 +1127,7 @@ int fr_render_glyph(fr_ctx *ctx, const int16_t *points_xy, const uint32_t *conto
         hipError_t e = hipMemsetAsync(gs.d_rec_count, 0, 8, ctx->stream);
         if (e != hipSuccess) lrc = fail(FR_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    if (lrc == FR_OK) lrc = plan_launch(&pl, A0 + o_out, w, h);
+    if (lrc == FR_OK) lrc = plan_launch_direct(&pl, A0 + o_out, w, h);
     hipError_t e = hipSuccess;
     if (lrc == FR_OK && !zero_copy) e = hipMemcpyAsync(st + up, A0 + o_out, img_bytes, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -303,3 +303,50 @@ def test_whole_font_at_renderglyph_sizes_properties(ctx, oracle):
             got = host[j["out_y"][0]:j["out_y"][0] + j["h"][0], j["out_x"][0]:j["out_x"][0] + j["w"][0]]
             assert np.array_equal(got, ref), (mode, int(k))
     dgs.close()
+
+
+def test_graph_replay_equals_plain_launches(ctx, oracle, ascii_set):
+    """option "graph": a plan's launches (several classes, with and without the fork onto the second stream, the SDF's
+    three kernels) captured into a hipGraph at the first render to a destination and replayed afterwards — every replay,
+    a second destination (re-capture) and a render after an option change == the plain launches, byte for byte."""
+    import torch
+    gs = ascii_set.gs
+    W = 1021
+    parts, y = [], 0
+    for size in (20, 64, 150):
+        jb, h = glyph_dims_jobs(gs, size, ascii_set.g_upm, W)
+        jb["out_y"] += y
+        y += h + 1
+        parts.append(jb)
+    jobs = np.concatenate(parts)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    try:
+        for mode, n, center, overlap in ((fr.FR_GRAY_DEBUG, 1, False, 1), (fr.FR_COVERAGE_U8, 4, True, 2), (fr.FR_COVERAGE_U8, 2, True, 1),
+                                         (fr.FR_SDF_U8, 1, True, 2), (fr.FR_WINDING_I16, 1, False, 2)):
+            dt = torch.int16 if mode == fr.FR_WINDING_I16 else torch.uint8
+            ctx.set_option("overlap", overlap)
+            plan = fr.Plan(dgs, jobs, mode, n, fr.FR_SAMPLE_CENTER if center else fr.FR_SAMPLE_CORNER)
+            assert plan.describe().count("fr::") >= 2, plan.describe()          # several launches per render
+            want = torch.full((y, W), 0x5b, dtype=dt, device="cuda")
+            ctx.set_option("graph", 0)
+            plan.render(want.data_ptr(), W, y); ctx.sync()
+            ctx.set_option("graph", 1)
+            a = torch.full((y, W), 0x5b, dtype=dt, device="cuda")
+            b = torch.full((y, W), 0x5b, dtype=dt, device="cuda")
+            torch.cuda.synchronize()
+            plan.render(a.data_ptr(), W, y); ctx.sync()                          # capture + first launch
+            assert torch.equal(a, want), mode
+            a.fill_(0x5b); torch.cuda.synchronize()
+            plan.render(a.data_ptr(), W, y); plan.render(a.data_ptr(), W, y); ctx.sync()     # replays
+            assert torch.equal(a, want), mode
+            plan.render(b.data_ptr(), W, y); ctx.sync()                          # another destination: captured again
+            assert torch.equal(b, want), mode
+            ctx.set_option("overlap", 0)                                         # an option changed: captured again
+            a.fill_(0x5b); torch.cuda.synchronize()
+            ms = plan.render_timed(a.data_ptr(), W, y)
+            assert ms > 0 and torch.equal(a, want), mode
+            plan.close()
+    finally:
+        ctx.set_option("graph", 0)
+        ctx.set_option("overlap", 1)
+        dgs.close()
