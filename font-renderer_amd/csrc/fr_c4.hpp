@@ -31,7 +31,9 @@ constexpr uint32_t c4_lstride(int cap) { return (uint32_t)cap + 4u; }
 // cells), 0.343 -> 0.291 ms on 256^2 cells of 32 segments — and nothing at five (an odd number of waves per SIMD: DESIGN.md
 // section 4.0).  The instances that keep 32 crossings or more records are bound to four (three) by their LDS.
 // (the 1024-record instances: 77 KB of LDS, two workgroups per CU — the register budget of two waves per SIMD)
-constexpr int c4_occ(int cap, int wlog, int rpl) { return rpl >= 16 ? 2 : ((cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC); }
+// (the 512-record instances: 45 - 53 KB of LDS, three workgroups per CU — and a third of the register file each, which the
+// second register list of their two-pass bands needs: fr_cov4.hip, SPLIT)
+constexpr int c4_occ(int cap, int wlog, int rpl) { return rpl >= 16 ? 2 : (rpl >= 8 ? 3 : ((cap <= 16 && rpl == 2) ? FR_C4_OCC_SMALL : FR_C4_OCC)); }
 constexpr int w1_occ(int rpl, int wlog) { return rpl >= 16 ? 2 : ((rpl == 2) ? FR_W1_OCC_SMALL : FR_C4_OCC); }
 // 16 bytes of a row list (8-byte aligned): two 8-byte LDS accesses unless the rows are 16-byte aligned
 template <uint32_t LSTRIDE>

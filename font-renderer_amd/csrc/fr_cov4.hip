@@ -147,6 +147,10 @@ void cov4_kernel(const RenderArgs A)
     constexpr uint32_t NWIN = 1u << WLOG;           // 16-pixel windows per pixel row
     constexpr uint32_t PRB = L::PRB;                // pixel rows per wave band
     constexpr int LN = (NS == 4) ? 2 : 1;           // log2 NS
+    // SPLIT: the instances of many records (glyphs of > 256 segments: wiggly outlines whose over-full rows come dozens to
+    // a band) can walk a band's pairs again in two halves of the sample columns — a 64-crossing tier out of two 32-slot
+    // passes, no LDS of its own (below) — instead of settling every over-full row by its own direct sum
+    constexpr bool SPLIT = RPL >= 8 && CAP == 32;
     extern __shared__ __align__(16) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -205,19 +209,21 @@ void cov4_kernel(const RenderArgs A)
         // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
         const float cy = ((float)(job.max_y - (int32_t)(y0 + (lane >> LN))) - sub_off((int)(lane & (uint32_t)(NS - 1)), NS, phase)) / job.scale;
         uint16_t *mylist = s_lists + lane * LSTRIDE;
-        {
+        auto init_lists = [&]() {
             const uint4 ones = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
 #pragma unroll
             for (uint32_t q = 0; q < CAP / 8u; ++q) c4_st16<LSTRIDE>(mylist + 8u * q, ones);
-        }
+            s_cnt[lane] = 0u;
+        };
+        init_lists();
         s_cy[lane] = cy;
-        s_cnt[lane] = 0u;
 
         // ---- layout + evaluation.  The band's (record, row) pairs form ONE sequence, record by record (lane by lane,
         // a lane's records in order); it is walked in chunks of PCAP pairs — only the markers are per chunk, the row
         // offsets and the running record index carry over — 64 pairs per trip, every trip but the last one full.
+        uint32_t c[RPL], off0 = 0u, tot;
         {
-            uint32_t c[RPL], r0[RPL], csum = 0;
+            uint32_t r0[RPL], csum = 0;
             {
                 const uint32_t lo = row_b0, hi = row_b0 + 64u;
 #pragma unroll
@@ -229,9 +235,9 @@ void cov4_kernel(const RenderArgs A)
                 }
             }
             const uint32_t incl = c4_wave_incl_add(csum);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (tot) {
-                const uint32_t off0 = incl - csum;
+                off0 = incl - csum;
                 {
                     uint32_t off = off0, ro[RPL];
 #pragma unroll
@@ -249,6 +255,13 @@ void cov4_kernel(const RenderArgs A)
                                                                                                   ro[8 * q8 + 4] | (ro[8 * q8 + 5] << 16), ro[8 * q8 + 6] | (ro[8 * q8 + 7] << 16));
                 }
                 }
+            }
+        }
+        // one walk of the band's pairs; SPLIT instances can walk again keeping only the crossings with J - 1 in
+        // [jlo, jlo + jspan) (every instance's first walk keeps J in 1 .. NCOL: all but the ones left of the strip)
+        auto eval_pass = [&](uint32_t jlo, uint32_t jspan) {
+            (void)jlo; (void)jspan;
+            if (tot) {
                 const uint32_t npairs = tot;
                 uint32_t carry = 0u;               // record index (+ 1) of the last pair walked so far
               for (uint32_t base = 0; base < npairs; base += (uint32_t)C4_PCAP) {
@@ -326,7 +339,9 @@ void cov4_kernel(const RenderArgs A)
                                     while (s_cxp[J] > xx) --J;
                                 }
                             }
-                            if (livep & (J > 0)) {
+                            bool keep = livep & (J > 0);
+                            if constexpr (SPLIT) keep = livep & ((uint32_t)(J - 1) - jlo < jspan);
+                            if (keep) {
                                 const uint32_t pos = atomicAdd(&s_cnt[row & 63u], 1u);
                                 uint16_t *rowlist = s_lists + __umul24(row & 63u, LSTRIDE);
                                 rowlist[min(pos, (uint32_t)CAP)] = (uint16_t)(((uint32_t)J << 2) | code);   // (slot CAP: the dump)
@@ -348,9 +363,10 @@ void cov4_kernel(const RenderArgs A)
                 c4_wave_lds_sync();
               }
             }
-        }
+        };
+        eval_pass(0u, NCOL);
         C4_ABL_EVAL_ONLY();
-        const uint32_t cnt = s_cnt[lane];
+        uint32_t cnt = s_cnt[lane];
         uint8_t *const out_band = reinterpret_cast<uint8_t *>(A.out) + ((size_t)job.out_y + y0) * A.out_stride + job.out_x + x0s;
         const uint32_t wx = lane & (NWIN - 1u);
         // pixel rows of this band that lie in the cell; `edge`: the band or the strip is cut by the cell's border
@@ -369,33 +385,71 @@ void cov4_kernel(const RenderArgs A)
             continue;
         }
         // ---- pull my list into registers and sort it by J (network size = the wave's fullest row)
-        const bool ovf = cnt > (uint32_t)CAP;
-        uint32_t d[16];
-        uint32_t Hcur, maxcnt;
-        {
+        auto pull_sort = [&](uint32_t (&dd)[16], uint32_t n, bool blank, uint32_t &H, uint32_t &mx) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint4 v = make_uint4(0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu, 0xfffdfffdu);
-                if (q < CAP / 8 && (q == 0 || __ballot(cnt > (uint32_t)(8 * q)) != 0ull)) v = c4_ld16<LSTRIDE>(mylist + 8 * q);
-                d[4 * q + 0] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+                if (q < CAP / 8 && (q == 0 || __ballot(n > (uint32_t)(8 * q)) != 0ull)) v = c4_ld16<LSTRIDE>(mylist + 8 * q);
+                dd[4 * q + 0] = v.x; dd[4 * q + 1] = v.y; dd[4 * q + 2] = v.z; dd[4 * q + 3] = v.w;
+            }
+            if (__ballot(blank)) {
+                // over-full rows are settled by the direct sum below: their lists must add nothing
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dd[q] = blank ? 0xfffdfffdu : dd[q];
+            }
+            if (CAP > 16 && __ballot(n > 16u && !blank) != 0ull) {
+                c4_packed_sort<16>(dd); H = 16u;
+                mx = __ballot(n > 28u) ? 32u : (__ballot(n > 24u) ? 28u : (__ballot(n > 20u) ? 24u : 20u));
+            } else if (CAP > 8 && __ballot(n > 8u && !blank) != 0ull) {
+                c4_packed_sort<8>(dd); H = 8u;
+                mx = __ballot(n > 12u) ? 16u : 12u;
+            } else {
+                c4_packed_sort<4>(dd); H = 4u;
+                mx = __ballot(n > 4u) ? 8u : 4u;
+            }
+        };
+        bool ovf = cnt > (uint32_t)CAP;
+        uint32_t d[16];
+        uint32_t Hcur, maxcnt;
+        // SPLIT: the crossings left of the strip's middle, when the band was walked in two halves
+        [[maybe_unused]] uint32_t dl[SPLIT ? 16 : 1];
+        [[maybe_unused]] uint32_t Hl = 0u, maxl = 0u;
+        [[maybe_unused]] bool split = false;
+        if constexpr (SPLIT) {
+            // Over-full rows come in bands (a wiggly outline crosses dozens of neighbouring rows 40 - 60 times): with three
+            // or more of them the wave walks the band's pairs twice more, once keeping the crossings of the right half of
+            // the sample columns and once those of the left half — 32 slots each, the right half pulled into registers
+            // before the left half reuses the lists — and the toggle walk below runs through one after the other (every
+            // crossing of the right half lies right of every one of the left).  A row that overflows a half still takes
+            // the direct sum.  Three walks instead of one, against ~1 100 vector instructions per over-full row.
+#ifdef FR_C4_STATS
+            const int n0 = __popcll(__ballot(ovf));
+            if (lane == 0) {
+                if (n0) { atomicAdd(&g_c4_stats[9], 1ull); atomicAdd(&g_c4_stats[10], (unsigned long long)n0); }   // bands with over-full rows / such rows, first walk
+                if (n0 >= 3) { atomicAdd(&g_c4_stats[11], 1ull); atomicAdd(&g_c4_stats[12], (unsigned long long)n0); }   // bands walked in halves / their rows
+            }
+#endif
+            if (__popcll(__ballot(ovf)) >= 3) {
+                split = true;
+                init_lists();
+                eval_pass(NCOL / 2u, NCOL / 2u);             // J in (NCOL / 2, NCOL]
+                const uint32_t cr = s_cnt[lane];
+                pull_sort(d, cr, cr > (uint32_t)CAP, Hcur, maxcnt);
+                c4_wave_lds_sync();
+                init_lists();
+                eval_pass(0u, NCOL / 2u);                    // J in [1, NCOL / 2]
+                const uint32_t cl = s_cnt[lane];
+                pull_sort(dl, cl, cl > (uint32_t)CAP, Hl, maxl);
+                ovf = (cr > (uint32_t)CAP) | (cl > (uint32_t)CAP);
+                if (__ballot(ovf)) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { d[q] = ovf ? 0xfffdfffdu : d[q]; dl[q] = ovf ? 0xfffdfffdu : dl[q]; }
+                }
+                cnt = cr + cl;
             }
         }
+        if (!split) pull_sort(d, cnt, ovf, Hcur, maxcnt);
         const unsigned long long ovf_rows = __ballot(ovf);
-        if (ovf_rows) {
-            // over-full rows are settled by the direct sum below: their lists must add nothing
-#pragma unroll
-            for (int q = 0; q < 16; ++q) d[q] = ovf ? 0xfffdfffdu : d[q];
-        }
-        if (CAP > 16 && __ballot(cnt > 16u && !ovf) != 0ull) {
-            c4_packed_sort<16>(d); Hcur = 16u;
-            maxcnt = __ballot(cnt > 28u) ? 32u : (__ballot(cnt > 24u) ? 28u : (__ballot(cnt > 20u) ? 24u : 20u));
-        } else if (CAP > 8 && __ballot(cnt > 8u && !ovf) != 0ull) {
-            c4_packed_sort<8>(d); Hcur = 8u;
-            maxcnt = __ballot(cnt > 12u) ? 16u : 12u;
-        } else {
-            c4_packed_sort<4>(d); Hcur = 4u;
-            maxcnt = __ballot(cnt > 4u) ? 8u : 4u;
-        }
         c4_wave_lds_sync();                        // the list region becomes E below
 #ifdef FR_C4_STATS
         // diagnostic build only (make variant NAME=c4stats DEFS=-DFR_C4_STATS): per wave band — sort tier, crossings, over-full rows
@@ -453,18 +507,22 @@ void cov4_kernel(const RenderArgs A)
                 }
                 zero = z;
             };
+            auto walk = [&](const uint32_t (&dd)[16], uint32_t H, uint32_t mx) {
 #pragma unroll
-            for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
-                if ((uint32_t)(4 * gq) >= Hcur || Hcur + (uint32_t)(4 * gq) >= maxcnt) continue;     // wave-uniform
+                for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
+                    if ((uint32_t)(4 * gq) >= H || H + (uint32_t)(4 * gq) >= mx) continue;           // wave-uniform
 #pragma unroll
-                for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(d[j], 16);
-            }
+                    for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(dd[j], 16);
+                }
 #pragma unroll
-            for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
-                if ((uint32_t)(4 * gq) >= Hcur || (uint32_t)(4 * gq) >= maxcnt) continue;            // wave-uniform
+                for (int gq = CAP / 8 - 1; gq >= 0; --gq) {
+                    if ((uint32_t)(4 * gq) >= H || (uint32_t)(4 * gq) >= mx) continue;               // wave-uniform
 #pragma unroll
-                for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(d[j], 0);
-            }
+                    for (int j = 4 * gq + 3; j >= 4 * gq; --j) slot(dd[j], 0);
+                }
+            };
+            walk(d, Hcur, maxcnt);
+            if constexpr (SPLIT) { if (split) walk(dl, Hl, maxl); }
             // the row's constant: NS [w(0) != 0], into byte 0 of the pixel row
             if (run != 0) atomicAdd(reinterpret_cast<uint32_t *>(erow), (uint32_t)NS);
         }

@@ -350,3 +350,49 @@ def test_graph_replay_equals_plain_launches(ctx, oracle, ascii_set):
         ctx.set_option("graph", 0)
         ctx.set_option("overlap", 1)
         dgs.close()
+
+
+def _comb_with_diamonds(teeth, n_diamonds, x_lo, x_hi, y_lo, y_hi, seed):
+    """a comb (2 * teeth crossings per ray through the teeth) + small diamond contours that only add SEGMENTS (and so move
+    the glyph into the fast kernels' 512-record instances) — spread over [x_lo, x_hi] x [y_lo, y_hi]"""
+    cs, _ = comb_glyph(teeth)
+    rng = np.random.default_rng(seed)
+    contours = [Contour(c) for c in cs]
+    for _ in range(n_diamonds):
+        cx, cy, r = int(rng.integers(x_lo, x_hi)), int(rng.integers(y_lo, y_hi)), int(rng.integers(6, 30))
+        poly = np.array([(cx - r, cy), (cx, cy + r), (cx + r, cy), (cx, cy - r)], np.int64)
+        nxt = np.roll(poly, -1, 0)
+        pts = np.empty((9, 2), np.int64)
+        pts[0:-1:2] = poly
+        pts[1:-1:2] = (poly + nxt) // 2
+        pts[-1] = poly[0]
+        contours.append(Contour(pts.astype(np.int16)))
+    allp = np.concatenate([c.points for c in contours])
+    return Glyph(Box(int(allp[:, 0].min()), int(allp[:, 1].min()), int(allp[:, 0].max()), int(allp[:, 1].max())), contours)
+
+
+def test_bands_of_overfull_rows_walk_in_two_halves(ctx, oracle):
+    """the 512-record instances (glyphs of 257 .. 384 segments) walk a band with three or more over-full rows twice more —
+    right half of the sample columns, then left half, 32 slots each — instead of one direct sum per row.  Glyphs whose
+    rays meet 50 crossings spread over the whole width (both halves fit), the same comb squeezed into the left 45 % of
+    the cell (the left half overflows: those rows still take the direct sum), 70 crossings, and wiggly synthetic
+    outlines of 300 segments; 4 x 4 and 2 x 2 samples, 256- / 128- / 64-pixel strips, ragged cells — all == the oracle."""
+    gl = [_comb_with_diamonds(25, 45, 150, 1850, 110, 290, 1),          # 50 crossings per ray, 25 + 25
+          _comb_with_diamonds(25, 45, 2000, 4100, 100, 1600, 2),        # the comb in the left half: 50 + 2
+          _comb_with_diamonds(35, 30, 150, 1850, 110, 290, 3),          # 70 crossings per ray: 35 + 35, both halves overflow
+          _comb_with_diamonds(20, 50, 150, 1850, 110, 1600, 4)]         # 40 (+ a few) crossings
+    sg = synth_glyphset(4, 300, first_index=4242)
+    gl += [sg.glyph(i) for i in range(len(sg))]
+    gs = GlyphSet(gl)
+    # every glyph fills its cell's width (the cell's origin is the glyph's own lower-left corner)
+    upm = np.array([int((g.box.x_max - g.box.x_min) * 1.04) for g in gl[:4]] + [2048] * len(sg), np.uint16)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    for cell_w, cell_h, cols in ((256, 256, 4), (128, 128, 4), (250, 141, 3), (61, 77, 5)):
+        cell = max(cell_w, cell_h)
+        jobs = cell_jobs(gs, cell, cell_w, upm, cols)
+        jobs["w"] = cell_w; jobs["h"] = cell_h
+        shape = (int((jobs["out_y"] + jobs["h"]).max()) + 1, int((jobs["out_x"] + jobs["w"]).max()) + 3)
+        for n in (4, 2):
+            got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, O.COVERAGE_U8, shape, n, True, dgs, 0, ["cov4_kernel<", ", 32, 8, "])
+            assert np.array_equal(got, ref), (cell_w, cell_h, n, desc)
+    dgs.close()

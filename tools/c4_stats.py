@@ -34,4 +34,5 @@ print(json.dumps({"workload": sys.argv[1], "cells": len(jobs), "wave_bands_with_
                   "sort_tier_share": {"8_slots": round(t8 / bands, 4), "16_slots": round(t16 / bands, 4), "32_slots": round(t32 / bands, 4)},
                   "crossings_per_sample_row": round(cross / rows, 3),
                   "rows_share": {"gt8": round(r8 / rows, 5), "gt16": round(r16 / rows, 5), "over_full_gt32": round(r32 / rows, 6)},
-                  "over_full_rows": ovf}))
+                  "over_full_rows": ovf,
+                  "first_walk": {"bands_with_over_full_rows": int(st[9]), "their_rows": int(st[10]), "bands_walked_in_halves": int(st[11]), "their_rows_": int(st[12])}}))
