@@ -17,6 +17,9 @@ namespace fr {
 #ifndef FR_C4_OCC_SMALL
 #define FR_C4_OCC_SMALL 6
 #endif
+#ifndef FR_DYN_BANDS
+#define FR_DYN_BANDS 1
+#endif
 #ifndef FR_W1_OCC_SMALL
 #define FR_W1_OCC_SMALL 6
 #endif

@@ -174,6 +174,8 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *wregion = smem + L::OFF_WAVES + (size_t)wave * L::WAVE;
     uint32_t *s_wcnt = reinterpret_cast<uint32_t *>(smem + L::OFF_WCNT);
 
+    uint32_t *const s_next_band = s_wcnt + 15;                              // (the set-up's barriers order this store)
+    if (tid == 0u) *s_next_band = band_first + NW;
     const uint32_t rec_cnt = c4_setup<NW, RCAP, NS, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES));
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale * (float)NS;
@@ -201,9 +203,19 @@ void cov4_kernel(const RenderArgs A)
     unsigned char *s_E = wregion;
 
     C4_ABL_SETUP_ONLY();
+    // (no workgroup barrier below: waves are independent.)  Every wave starts on band `wave` of the group and then takes
+    // the next band nobody has started yet (one LDS counter): bands differ a lot in cost — the margins above and below the
+    // glyph are nearly free — and a workgroup keeps its LDS until its slowest wave is done.  (Measured, same box: C3 - 1.7 %,
+    // S = 256 - 6 %, configs[3]'s shard - 1 %; win1_kernel keeps the static round-robin: there the same change cost its
+    // 128-pixel cells 18 %.)
+#if FR_DYN_BANDS
+    for (uint32_t band = band_first + wave; band < band_end;
+         band = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0u ? atomicAdd(s_next_band, 1u) : 0u))) {
+#else
     for (uint32_t band0 = band_first; band0 < band_end; band0 += NW) {
         const uint32_t band = band0 + wave;
-        if (band >= band_end) break;               // (no workgroup barrier below: waves are independent)
+        if (band >= band_end) break;
+#endif
         const uint32_t y0 = band * PRB;
         const uint32_t row_b0 = band * 64u;
         // ray height of sample row `lane` of the band: cy = (f32(max_y - y) - off(jj)) / scale  (:27)
