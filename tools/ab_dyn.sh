@@ -1,10 +1,11 @@
 #!/bin/bash
-# same-box A/B: bands dealt dynamically to the waves of a workgroup (main) vs the static round-robin (variant dyn0)
+# same-box A/B: bands dealt dynamically to the waves of a workgroup (main) vs the static round-robin (variant dyn0: -DFR_DYN_BANDS=0)
 out=$GRAFT_REPO_ROOT/gpurun_out/dyn; mkdir -p $out
 cd $GRAFT_REPO_ROOT
-for w in c3_cjk21k_256px_s128_16spp c4_bmp_shard_128px_s32_16spp c3_cjk21k_256px_s32_16spp c3_strokes21k_256px_s128_16spp real_dejavuserif_italic_whole_font_256px_16spp \
+WL=${WL:-"c3_cjk21k_256px_s128_16spp c4_bmp_shard_128px_s32_16spp c3_cjk21k_256px_s32_16spp c3_strokes21k_256px_s128_16spp real_dejavuserif_italic_whole_font_256px_16spp \
   real_dejavuserif_italic_whole_font_256px_gray_debug c3_cjk21k_256px_s128_gray_debug c4_bmp_shard_128px_s32_gray_debug c2_ascii95_128px_s32_16spp_x64pages \
-  real_dejavuserif_italic_renderglyph_dims_sizes12to256_16spp real_dejavuserif_italic_renderglyph_dims_sizes12to256_gray_debug c3_cjk21k_256px_s256_16spp c5_sdf_shard_512px_s64; do
+  real_dejavuserif_italic_renderglyph_dims_sizes12to256_16spp real_dejavuserif_italic_renderglyph_dims_sizes12to256_gray_debug c3_cjk21k_256px_s256_16spp c5_sdf_shard_512px_s64"}
+for w in $WL; do
   for rep in 1 2; do
   for v in main dyn0; do
     lib=font-renderer_amd/libfr_raster_var_$v.so; [ $v = main ] && lib=font-renderer_amd/libfr_raster.so
