@@ -732,6 +732,9 @@ static int plan_check(fr_plan *plan, void *out_dev, size_t out_stride, size_t ou
     if (plan->need_cols > out_stride || plan->need_rows > out_rows)
         return fail(FR_E_INVALID, "jobs need %llu x %llu elements, output is %zu x %zu",
                     (unsigned long long)plan->need_cols, (unsigned long long)plan->need_rows, out_stride, out_rows);
+    // (the fast kernels address the rows of a wave band by 32-bit offsets from the band's base: 32 rows of the pitch)
+    if (out_stride > ((size_t)1 << 26))
+        return fail(FR_E_INVALID, "row pitch of %zu elements: at most 2^26", out_stride);
     return FR_OK;
 }
 

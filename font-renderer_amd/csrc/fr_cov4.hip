@@ -153,7 +153,10 @@ void cov4_kernel(const RenderArgs A)
     constexpr bool SPLIT = RPL >= 8 && CAP == 32;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // (the wave index as a SCALAR: everything a band derives from it — rows, ray heights' base, the output address — is then
+    // scalar arithmetic and the stores take the band's base from SGPRs; `tid >> 6` alone is a vector value to the compiler)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
     if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
     if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
@@ -683,9 +686,21 @@ void cov4_kernel(const RenderArgs A)
         constexpr uint32_t K1 = 0x01010101u;
         // (one window pass: the hot form stores whole windows; a band or strip cut by the cell's border runs the same
         // arithmetic in a loop of its own — rolled, clipped stores — so that the hot loop stays as small as it was)
+        // (The window addresses depend on the lane only, so the compiler computes them once per kernel, keeps them live across
+        // the band loop and — in the 80-register instances — spills them; every reload is then a scratch load, and on gfx9 a
+        // wave waits for a load with s_waitcnt vmcnt(0), which also waits for every pixel store it still has in flight: a band's
+        // stores went out one HBM round trip at a time.  An opaque copy of the lane per band keeps the addresses where they
+        // are used — a few integer instructions per window instead; and the store address is a 32-bit offset from the band's
+        // wave-uniform base: PRB rows of < 2^27 bytes, fr_plan_render checks the pitch.)
+        uint32_t lane_w = lane;
+        asm volatile("" : "+v"(lane_w));
+        const uint32_t wxw = lane_w & (NWIN - 1u);
+        // (my window of pass 0, in E and in the output; pass `it` is 64 >> WLOG rows further down: a constant / a scalar away)
+        const unsigned char *const e_lane = s_E + (lane_w >> WLOG) * L::EROW + 16u * wxw;
+        const uint32_t out_lane = (lane_w >> WLOG) * (uint32_t)A.out_stride + 16u * wxw;
         auto window_pass = [&](uint32_t it, auto clipped) {
-            const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
-            const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
+            const uint32_t prow = (lane_w >> WLOG) + it * (64u >> WLOG);
+            const uint4 e = *reinterpret_cast<const uint4 *>(e_lane + it * (64u >> WLOG) * L::EROW);
             // inclusive byte prefix inside each dword: bytes 16 (i + 1) + sums; back to a bias of 16 per byte
             uint32_t x0 = e.x * K1, x1 = e.y * K1, x2 = e.z * K1, x3 = e.w * K1;
             x0 -= 0x30201000u;
@@ -703,9 +718,9 @@ void cov4_kernel(const RenderArgs A)
             } else {
                 // 8 (4) windows per pixel row: two (four) pixel rows share a DPP row — keep the scan inside each part
                 uint32_t s;
-                s = c4_dpp0<0x111>(inc); inc += (wx >= 1u) ? s : 0u;
-                s = c4_dpp0<0x112>(inc); inc += (wx >= 2u) ? s : 0u;
-                if (WLOG == 3) { s = c4_dpp0<0x114>(inc); inc += (wx >= 4u) ? s : 0u; }
+                s = c4_dpp0<0x111>(inc); inc += (wxw >= 1u) ? s : 0u;
+                s = c4_dpp0<0x112>(inc); inc += (wxw >= 2u) ? s : 0u;
+                if (WLOG == 3) { s = c4_dpp0<0x114>(inc); inc += (wxw >= 4u) ? s : 0u; }
             }
             const uint32_t cin = inc - T;                                   // in [0, NS^2]
             const uint32_t cb4 = __builtin_amdgcn_perm(cin, cin, 0x00000000u);
@@ -726,9 +741,9 @@ void cov4_kernel(const RenderArgs A)
                 return r;
             };
             const uint4 v = make_uint4(map4(x0), map4(x1), map4(x2), map4(x3));
-            unsigned char *dst = out_band + (size_t)prow * A.out_stride + 16u * wx;
+            unsigned char *dst = (out_band + (size_t)(it * (64u >> WLOG)) * A.out_stride) + out_lane;
             if (!decltype(clipped)::value) c4_store16(dst, v);
-            else c4_store_clip(dst, v, prow < hlim ? (int)wlim - (int)(16u * wx) : 0);
+            else c4_store_clip(dst, v, prow < hlim ? (int)wlim - (int)(16u * wxw) : 0);
         };
         if (C4_ABL_KEEP(1)) {
             if (__builtin_expect(!edge, 1)) {

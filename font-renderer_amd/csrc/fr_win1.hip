@@ -104,7 +104,12 @@ void win1_kernel(const RenderArgs A)
     constexpr uint32_t ESZ = (MODE == MODE1_WINDING_I16) ? 2u : 1u;
     extern __shared__ __align__(16) unsigned char smem[];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // (the wave index as a SCALAR: everything a band derives from it — rows, ray heights' base, the output address — is then
+    // scalar arithmetic and the stores take the band's base from SGPRs; `tid >> 6` alone is a vector value to the compiler)
+    // (one instance is left exactly as the compiler liked it — six workgroups per CU on 256-pixel strips, the real font's
+    // gray maps: every variant of these changes measured 2 - 4 % slower there; see also PLAIN below)
+    const uint32_t wave = (WLOG == 4 && RPL == 2) ? (tid >> 6) : (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint32_t bid = blockIdx.x, strip = 0, bgrp = 0;
     if (A.strips != 1u) { strip = bid % A.strips; bid /= A.strips; }
     if (A.band_groups != 1u) { bgrp = bid % A.band_groups; bid /= A.band_groups; }
@@ -133,7 +138,8 @@ void win1_kernel(const RenderArgs A)
         __syncthreads();
         cyt = t;
     }
-    const uint32_t rec_cnt = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES), cyt);
+    const uint32_t rec_cnt_v = c4_setup<NW, RCAP, 1, NCOL>(A, job, seg0, nseg, x0s, phase, s_cxp, s_rec, s_wcnt, reinterpret_cast<uint32_t *>(smem + L::OFF_WAVES), cyt);
+    const uint32_t rec_cnt = (WLOG == 4 && RPL == 2) ? rec_cnt_v : (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_cnt_v);   // (workgroup-uniform: a scalar)
     const int32_t min_xs = job.min_x + (int32_t)x0s;
     const float jscale = job.scale;
     const float joff = (float)min_xs + soff - 1.0f;
@@ -410,10 +416,28 @@ void win1_kernel(const RenderArgs A)
         // (one window pass: the hot form stores whole windows; a band or strip cut by the cell's border runs the same
         // arithmetic in a loop of its own — rolled, clipped stores — so that the hot loop stays as small as it was)
         uint32_t band_bits[(W1_ROWS * NWIN) / 64u];                         // (sign-bit mode, 256-pixel strips: my windows' bits, staged below)
+        // (the window addresses depend on the lane only, so the compiler computes them once per kernel, keeps them live
+        // across the band loop and — in the 80-register instances — spills them; every reload is then a scratch load, and
+        // on gfx9 a wave waits for a load with s_waitcnt vmcnt(0), which also waits for every pixel store it has in flight:
+        // the stores of a band went out one HBM round trip at a time.  An opaque copy of the lane per band keeps the
+        // addresses where they are used: a few integer instructions per window instead.)
+        uint32_t lane_w = lane;
+#ifndef FR_W1_LAUNDER_ALL
+        if constexpr (!(WLOG == 4 && RPL == 2))
+#endif
+        asm volatile("" : "+v"(lane_w));
+        const uint32_t wx = lane_w & (NWIN - 1u);
+        // my window of pass 0, in E and in the output (a 32-bit offset from the band's wave-uniform base: 16 rows of < 2^27
+        // bytes — fr_plan_render checks the pitch); pass `it` is 64 >> WLOG rows further down: a constant / a scalar away
+        const unsigned char *const e_lane = s_E + (lane_w >> WLOG) * L::EROW + 16u * wx;
+        const uint32_t out_lane = (lane_w >> WLOG) * (uint32_t)row_bytes + (16u * wx) * ESZ;
         auto window_pass = [&](uint32_t it, auto clipped) {
             constexpr bool edge = decltype(clipped)::value;
-            const uint32_t prow = (lane >> WLOG) + it * (64u >> WLOG);
-            const uint4 e = *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx);
+            const uint32_t prow = (lane_w >> WLOG) + it * (64u >> WLOG);
+            // (the six-workgroup instance of 256-pixel strips keeps the plain addresses: measured 4 % faster that way)
+            constexpr bool PLAIN = (WLOG == 4 && RPL == 2);
+            const uint4 e = PLAIN ? *reinterpret_cast<const uint4 *>(s_E + prow * L::EROW + 16u * wx)
+                                  : *reinterpret_cast<const uint4 *>(e_lane + it * (64u >> WLOG) * L::EROW);
             // bytes 32 + d: inclusive prefix inside each dword gives 32 (i + 1) + sums; then a bias of 64 per byte
             uint32_t x0 = e.x * K1, x1 = e.y * K1, x2 = e.z * K1, x3 = e.w * K1;
             x0 += 0xbfe00020u;                                              // + 32, 0, - 32, - 64 per byte
@@ -440,7 +464,8 @@ void win1_kernel(const RenderArgs A)
             const uint32_t p0 = x0, p1 = x1, p2 = x2, p3 = x3;              // (pixel order: byte x of the row is pixel x)
             const bool direct = (ovf_rows >> prow) & 1u;                    // stored by the direct path above
             if (MODE != MODE1_BITS && direct) return;                       // (the sign-bit store gathers across the lanes: all stay)
-            unsigned char *dst = out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ;
+            unsigned char *dst = PLAIN ? out_band + (size_t)prow * row_bytes + (size_t)(16u * wx) * ESZ
+                                       : (out_band + (size_t)(it * (64u >> WLOG)) * row_bytes) + out_lane;
             const int mclip = prow < hlim ? (int)wlim - (int)(16u * wx) : 0;   // (edge only) pixels of my window inside the cell
             if (MODE == MODE1_BITS) {
                 // bit 7 of every byte <- (w != 0), then the four bits of a dword gathered by one multiply
@@ -452,7 +477,7 @@ void win1_kernel(const RenderArgs A)
                 };
                 const uint32_t bits16 = (b4(p0) & 15u) | ((b4(p1) & 15u) << 4) | ((b4(p2) & 15u) << 8) | ((b4(p3) & 15u) << 12);
                 if (WLOG == 4) band_bits[it] = bits16;                      // (a 256-pixel strip: the whole band leaves at once, below)
-                else w1_store_bits<WLOG>(out_band + (size_t)prow * row_bytes, wx, bits16, prow < hlim && !direct);
+                else w1_store_bits<WLOG>(out_band + prow * (uint32_t)row_bytes, wx, bits16, prow < hlim && !direct);
             } else if (MODE == MODE1_MASK) {
                 auto m4 = [](uint32_t x) -> uint32_t {
                     const uint32_t z = x ^ 0x60606060u;                     // 0 where w == 0 (bytes < 0x80)
