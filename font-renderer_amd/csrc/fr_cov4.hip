@@ -209,8 +209,8 @@ void cov4_kernel(const RenderArgs A)
     // (no workgroup barrier below: waves are independent.)  Every wave starts on band `wave` of the group and then takes
     // the next band nobody has started yet (one LDS counter): bands differ a lot in cost — the margins above and below the
     // glyph are nearly free — and a workgroup keeps its LDS until its slowest wave is done.  (Measured, same box: C3 - 1.7 %,
-    // S = 256 - 6 %, configs[3]'s shard - 1 %; win1_kernel keeps the static round-robin: there the same change cost its
-    // 128-pixel cells 18 %.)
+    // S = 256 - 6 %, configs[3]'s shard - 1 %; win1_kernel keeps the static round-robin: on its large cells the dealing was
+    // worth 0.3 %.)
 #if FR_DYN_BANDS
     for (uint32_t band = band_first + wave; band < band_end;
          band = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0u ? atomicAdd(s_next_band, 1u) : 0u))) {

@@ -146,7 +146,8 @@ void fr_plan_destroy(fr_plan *plan);
  * themselves, in LDS ("fused", decided per job); the precompute kernel is re-run first for the larger glyphs only.
  * Asynchronous on the context's stream.  out_dev: DEVICE pointer to an array of
  * out_rows rows of out_stride elements (u8, or i16 for FR_WINDING_I16); every job
- * must fit inside it (checked).  Pixels outside all jobs are not touched.           */
+ * must fit inside it (checked); out_stride <= 2^26 elements (FR_E_INVALID beyond: the kernels address the rows of a
+ * wave band by 32-bit offsets from the band's base).  Pixels outside all jobs are not touched.                     */
 int fr_plan_render(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows);
 /* same, bracketed by HIP events on the launch stream; synchronous; *ms = kernel time */
 int fr_plan_render_timed(fr_plan *plan, void *out_dev, size_t out_stride, size_t out_rows, float *ms);

@@ -396,3 +396,19 @@ def test_bands_of_overfull_rows_walk_in_two_halves(ctx, oracle):
             got, ref, desc = _both(ctx, oracle, gs, jobs, fr.FR_COVERAGE_U8, O.COVERAGE_U8, shape, n, True, dgs, 0, ["cov4_kernel<", ", 32, 8, "])
             assert np.array_equal(got, ref), (cell_w, cell_h, n, desc)
     dgs.close()
+
+
+def test_row_pitch_limit_is_checked(ctx, ascii_set):
+    """the fast kernels address the rows of a wave band by 32-bit offsets from the band's base: fr_plan_render refuses a
+    pitch above 2^26 elements (FR_E_INVALID) instead of rendering somewhere else"""
+    import torch
+    gs = ascii_set.gs
+    jobs, H = glyph_dims_jobs(gs, 20, ascii_set.g_upm, 509, n_glyphs=4)
+    dgs = fr.DeviceGlyphSet(ctx, gs)
+    plan = fr.Plan(dgs, jobs, fr.FR_GRAY_DEBUG, 1, fr.FR_SAMPLE_CORNER)
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception) as e:
+        plan.render(buf.data_ptr(), (1 << 26) + 1, H)
+    assert "pitch" in str(e.value)
+    plan.close()
+    dgs.close()
