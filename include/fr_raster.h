@@ -111,8 +111,8 @@ int fr_ctx_sync(fr_ctx *ctx);
  * smaller ones onto an internal second stream and joins them: 1 (default) for plans of >= 32 Mpixel — below that one
  * stream is quicker —, 2 always, 0 never), "graph" (1: the launches of a plan's render — fork and join included — are
  * captured into a hipGraph at the first fr_plan_render to a destination and replayed with one hipGraphLaunch afterwards;
- * captured again when the destination or an option changes.  Measured: worth 3 - 6 % on plans of eight or
- * more launches, a loss of ~5 us per render on plans of one to three; default 0), "min_wgs", "fuse_prepare", "lds_pad"   */
+ * captured again when the destination or an option changes.  Measured: worth 3 - 6 % on a plan of four
+ * launches forked over two streams, a loss of ~5 us per render on plans of one to three launches; default 0), "min_wgs", "fuse_prepare", "lds_pad"   */
 int fr_ctx_set_option(fr_ctx *ctx, const char *key, int64_t value);
 
 /* ---- glyph sets: Glyph[] flattened (Glyph.zig:11-24) ---------------------
